@@ -1,0 +1,21 @@
+"""CPU oracle for the decode hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import anything from this package.  The shipped path (the ``evc_amd`` package) never
+imports it and fails loudly when its HIP library is missing.
+
+What is restated here, and what pins it:
+
+* ``schedule.py`` / ``samplers.py`` / ``scorenet.py`` / ``upfirdn2d.py`` -- the diffusion
+  path (reference ``models/__init__.py``, ``models/pndm.py``,
+  ``models/better/{ncsnpp_more,layerspp,layers,up_or_down_sampling}.py``,
+  ``models/better/op/upfirdn2d.py``).  PINNED: ``tests/golden/make_goldens.py`` imports
+  the reference itself in the build container and stores its outputs as fixtures under
+  ``tests/golden/``; ``tests/test_oracle_goldens.py`` checks this restatement against them.
+* ``elic.py`` / ``entropy.py`` / ``rans.py`` -- the ELIC key-frame codec (reference
+  ``Network.py``, ``ELICUtilis/layers/layers.py``, ``Inference.py``) and the entropy
+  coder of third-party ``compressai==1.1.5`` (``requirements.txt:17``; not vendored, not
+  installed, so the reference ELIC modules cannot be imported here).
+  PARITY UNPINNED: written from the reference source text and from the published
+  compressai / ryg_rans algorithm; the reference holds no golden vector for this path.
+"""

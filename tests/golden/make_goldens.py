@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE's own diffusion code on CPU.
+
+Runs ONLY in the build container, where the reference is mounted read-only at /root/reference
+(it does not exist on the GPU box).  Nothing from the reference is copied: this script imports
+it, feeds it seeded inputs / seeded weights and stores inputs+outputs as small ``.npz`` fixtures
+next to this file.  Tests never import the reference; they rebuild the same seeded inputs and
+compare against the stored outputs.
+
+    python tests/golden/make_goldens.py            # all fixtures
+    python tests/golden/make_goldens.py --skip-full  # skip the full-size (262 M param) forward
+
+The ELIC path (Network.py / ELICUtilis) is NOT covered: it needs compressai/timm/thop/ptflops,
+none of which is installed here (ordinary ModuleNotFoundError) -- see oracle/__init__.py.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+from oracle.scorenet import Dims, seeded_params  # noqa: E402  (seed recipe shared with the tests)
+
+
+def d2n(d):
+    ns = argparse.Namespace()
+    for k, v in d.items():
+        setattr(ns, k, d2n(v) if isinstance(v, dict) else v)
+    return ns
+
+
+def ref_config(ngf, head, image_size):
+    cfg = yaml.safe_load(open(os.path.join(REF, "configs/mine.yml")))
+    cfg["model"]["ngf"] = ngf
+    cfg["model"]["n_head_channels"] = head
+    cfg["data"]["image_size"] = image_size
+    config = d2n(cfg)
+    config.device = torch.device("cpu")
+    return config
+
+
+def ref_net(ngf, head, image_size, seed):
+    from models.better.ncsnpp_more import UNetMore_DDPM
+    net = UNetMore_DDPM(ref_config(ngf, head, image_size)).eval()
+    d = Dims(ngf=ngf, n_head_channels=head, image_size=image_size)
+    p = seeded_params(d, seed)
+    own = dict(net.named_parameters())
+    assert set(own) == set(p), (sorted(set(own) ^ set(p))[:8])
+    for k, v in p.items():
+        assert tuple(own[k].shape) == tuple(v.shape), k
+    missing, unexpected = net.load_state_dict(p, strict=False)
+    assert not unexpected and all(m in ("betas", "alphas", "alphas_prev", "unet.sigmas") for m in missing), missing
+    return net, d
+
+
+def rnd(seed, *shape):
+    return torch.from_numpy(np.random.default_rng(seed).standard_normal(shape, dtype=np.float32))
+
+
+def save(name, **arrs):
+    out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()}
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def gen_schedule():
+    net, _ = ref_net(32, 32, 32, 1)
+    out = dict(betas=net.betas, alphas=net.alphas, alphas_prev=net.alphas_prev)
+    # the subsampled tables as the reference sampler derives them (models/__init__.py:231-239)
+    for S in (10, 50, 100):
+        skip = 1000 // S
+        steps = torch.tensor(list(range(0, 1000, skip)))
+        a = net.alphas.index_select(0, steps)
+        ap = torch.cat([a[1:], torch.tensor([1.0]).to(a)])
+        b = 1.0 - torch.div(a, ap)
+        out.update({f"steps_{S}": steps, f"alphas_{S}": a, f"alphas_prev_{S}": ap, f"betas_{S}": b})
+    save("schedule", **out)
+
+
+def gen_fir():
+    from models.better.up_or_down_sampling import upsample_2d, downsample_2d
+    x = rnd(11, 2, 6, 16, 16)
+    save("fir", x=x, up=upsample_2d(x, [1, 3, 3, 1], factor=2), down=downsample_2d(x, [1, 3, 3, 1], factor=2))
+    from models.better.op.upfirdn2d import upfirdn2d
+    x2 = rnd(12, 1, 3, 9, 7)
+    k = rnd(13, 3, 3)
+    save("upfirdn2d_generic", x=x2, k=k,
+         up2_pad10=upfirdn2d(x2, k, up=2, down=1, pad=(1, 0)),
+         down3_pad21=upfirdn2d(x2, k, up=1, down=3, pad=(2, 1)),
+         up3_down2_pad22=upfirdn2d(x2, k, up=3, down=2, pad=(2, 2)))
+
+
+def gen_blocks():
+    """Per-module outputs of a mid-sized net (ngf=64, head 64, 32x32) via forward hooks."""
+    net, d = ref_net(64, 64, 32, 21)
+    x, cond = rnd(22, 2, 15, 32, 32), rnd(23, 2, 6, 32, 32)
+    labels = torch.tensor([430, 430])
+    taps = {}
+    hooks = [m.register_forward_hook(lambda mod, i, o, idx=idx: taps.__setitem__(idx, o.detach().clone()))
+             for idx, m in enumerate(net.unet.all_modules)]
+    with torch.no_grad():
+        out = net(x, labels, cond=cond)
+    for h in hooks:
+        h.remove()
+    # strided samples of every module's output keep the file small but pin every block
+    samples = {}
+    for idx, t in taps.items():
+        flat = t.reshape(-1)
+        stride = max(1, flat.numel() // 512)
+        samples[f"tap{idx}"] = flat[::stride][:512].clone()
+        samples[f"tapstat{idx}"] = torch.stack([t.mean(), t.std()])
+    save("blocks_ngf64", out=out, labels=labels, **samples)
+
+
+def gen_forward_reduced():
+    net, d = ref_net(32, 32, 32, 31)
+    x, cond = rnd(32, 2, 15, 32, 32), rnd(33, 2, 6, 32, 32)
+    with torch.no_grad():
+        o0 = net(x, torch.tensor([0, 0]), cond=cond)
+        o1 = net(x, torch.tensor([990, 990]), cond=cond)
+        o2 = net(x, torch.tensor([-0.5, -0.5]), cond=cond)  # F-PNDM feeds fractional/negative labels
+    save("forward_ngf32", out_t0=o0, out_t990=o1, out_tm05=o2)
+
+
+def gen_samplers():
+    import models
+    from models import ddpm_sampler, ddim_sampler, FPNDM_sampler
+    net, d = ref_net(32, 32, 32, 41)
+    x_T, cond = rnd(42, 2, 15, 32, 32), rnd(43, 2, 6, 32, 32)
+    S = 5
+    noises = [rnd(100 + i, 2, 15, 32, 32) for i in range(S)]
+    it = iter(noises)
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **kw: next(it)   # inject the per-step noise the reference would draw
+    try:
+        ddpm = ddpm_sampler(x_T.clone(), net, cond=cond, subsample_steps=S, denoise=True, clip_before=True,
+                            final_only=True, t_min=-1, log=True)
+    finally:
+        torch.randn_like = orig
+    ddim = ddim_sampler(x_T.clone(), net, cond=cond, subsample_steps=S, denoise=True, clip_before=True,
+                        final_only=True, t_min=-1, log=True)
+    fp = FPNDM_sampler(x_T.clone(), net, cond=cond, subsample_steps=10, final_only=True, clip_before=True)
+    save("samplers_ngf32", ddpm=ddpm, ddim=ddim, fpndm=fp)
+
+    # label sequences (incl. the L-1 denoise label quirk and F-PNDM's fractional labels) with a fake net
+    class Fake(torch.nn.Module):
+        def __init__(self, real):
+            super().__init__()
+            self.alphas, self.alphas_prev, self.betas = real.alphas, real.alphas_prev, real.betas
+            self.type = "v1"
+            self.log = []
+
+        def forward(self, x, y, cond=None, cond_mask=None):
+            self.log.append(float(y[0]))
+            return 0.1 * x
+    out = {}
+    for nm, fn, kw in (("ddpm", ddpm_sampler, dict(subsample_steps=2, denoise=True)),
+                       ("ddim", ddim_sampler, dict(subsample_steps=4, denoise=True)),
+                       ("fpndm", FPNDM_sampler, dict(subsample_steps=4)),
+                       ("fpndm10", FPNDM_sampler, dict(subsample_steps=10)),
+                       ("ddpm100", ddpm_sampler, dict(subsample_steps=100, denoise=True))):
+        f = Fake(net)
+        fn(x_T.clone(), f, cond=cond, final_only=True, **kw)
+        out["labels_" + nm] = np.asarray(f.log, dtype=np.float64)
+    save("label_sequences", **out)
+
+
+def gen_forward_full():
+    torch.set_num_threads(8)
+    net, d = ref_net(192, 192, 128, 1234)
+    x, cond = rnd(51, 1, 15, 128, 128), rnd(52, 1, 6, 128, 128)
+    with torch.no_grad():
+        o = net(x, torch.tensor([500]), cond=cond)
+    flat = o.reshape(-1)
+    save("forward_full", samples=flat[::60].clone(), stats=torch.stack([o.mean(), o.std(), o.abs().max()]),
+         first_row=o[0, :, 0, :].clone())
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    gens = dict(schedule=gen_schedule, fir=gen_fir, blocks=gen_blocks, forward_reduced=gen_forward_reduced,
+                samplers=gen_samplers, forward_full=gen_forward_full)
+    for name, fn in gens.items():
+        if a.only and name != a.only:
+            continue
+        if a.skip_full and name == "forward_full":
+            continue
+        fn()

@@ -1,0 +1,130 @@
+"""The CPU oracle (oracle/) checked against fixtures produced by the reference itself
+(tests/golden/make_goldens.py).  This is what pins the oracle; nothing here touches the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rnd
+from oracle import samplers, schedule, scorenet, upfirdn2d
+from oracle.scorenet import Dims, seeded_params
+
+
+def test_schedule_tables():
+    g = golden("schedule")
+    betas, alphas, alphas_prev = schedule.base_schedule()
+    np.testing.assert_array_equal(betas.numpy(), g["betas"])
+    np.testing.assert_array_equal(alphas.numpy(), g["alphas"])
+    np.testing.assert_array_equal(alphas_prev.numpy(), g["alphas_prev"])
+    for S in (10, 50, 100):
+        steps, a, ap, b = schedule.subsample(alphas, alphas_prev, betas, S)
+        np.testing.assert_array_equal(steps.numpy(), g[f"steps_{S}"])
+        np.testing.assert_array_equal(a.numpy(), g[f"alphas_{S}"])
+        np.testing.assert_array_equal(ap.numpy(), g[f"alphas_prev_{S}"])
+        np.testing.assert_array_equal(b.numpy(), g[f"betas_{S}"])
+
+
+def test_fir_resampling_numpy_and_torch_forms():
+    g = golden("fir")
+    x = g["x"]
+    np.testing.assert_allclose(upfirdn2d.upsample_2d(x), g["up"], atol=2e-6)
+    np.testing.assert_allclose(upfirdn2d.downsample_2d(x), g["down"], atol=2e-6)
+    xt = torch.from_numpy(x)
+    np.testing.assert_allclose(scorenet.fir_up2(xt).numpy(), g["up"], atol=2e-6)
+    np.testing.assert_allclose(scorenet.fir_down2(xt).numpy(), g["down"], atol=2e-6)
+
+
+def test_upfirdn2d_generic():
+    g = golden("upfirdn2d_generic")
+    x, k = g["x"], g["k"]
+    np.testing.assert_allclose(upfirdn2d.upfirdn2d(x, k, up=2, down=1, pad=(1, 0)), g["up2_pad10"], atol=3e-6)
+    np.testing.assert_allclose(upfirdn2d.upfirdn2d(x, k, up=1, down=3, pad=(2, 1)), g["down3_pad21"], atol=3e-6)
+    np.testing.assert_allclose(upfirdn2d.upfirdn2d(x, k, up=3, down=2, pad=(2, 2)), g["up3_down2_pad22"], atol=3e-6)
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_blocks_every_module_output():
+    g = golden("blocks_ngf64")
+    d = Dims(ngf=64, n_head_channels=64, image_size=32)
+    p = seeded_params(d, 21)
+    x, cond = rnd(22, 2, 15, 32, 32), rnd(23, 2, 6, 32, 32)
+    taps = {}
+    out = scorenet.forward(p, d, x, torch.tensor([430, 430]), cond=cond, taps=taps)
+    assert _rel(out.numpy(), g["out"]) < 2e-5
+    mods = scorenet.program(d)
+    checked = 0
+    for idx, m in enumerate(mods):
+        if m["kind"] not in ("res", "attn", "conv3") or idx not in taps:
+            continue
+        t = taps[idx].reshape(-1)
+        stride = max(1, t.numel() // 512)
+        assert _rel(t[::stride][:512].numpy(), g[f"tap{idx}"]) < 2e-5, (idx, m)
+        checked += 1
+    assert checked >= 40
+
+
+def test_forward_reduced_labels_incl_fractional():
+    g = golden("forward_ngf32")
+    d = Dims(ngf=32, n_head_channels=32, image_size=32)
+    p = seeded_params(d, 31)
+    x, cond = rnd(32, 2, 15, 32, 32), rnd(33, 2, 6, 32, 32)
+    for key, lab in (("out_t0", [0, 0]), ("out_t990", [990, 990]), ("out_tm05", [-0.5, -0.5])):
+        out = scorenet.forward(p, d, x, torch.tensor(lab), cond=cond)
+        assert _rel(out.numpy(), g[key]) < 2e-5, key
+
+
+def _net(seed):
+    d = Dims(ngf=32, n_head_channels=32, image_size=32)
+    p = seeded_params(d, seed)
+    return d, p
+
+
+def test_sampler_trajectories():
+    g = golden("samplers_ngf32")
+    d, p = _net(41)
+    x_T, cond = rnd(42, 2, 15, 32, 32), rnd(43, 2, 6, 32, 32)
+    eps = lambda x, t: scorenet.forward(p, d, x, t, cond=cond)
+    sched = schedule.base_schedule()
+    noises = [rnd(100 + i, 2, 15, 32, 32) for i in range(5)]
+    out = samplers.ddpm(x_T.clone(), eps, sched, subsample_steps=5, noise_fn=lambda i, x: noises[i])
+    assert out.shape == g["ddpm"].shape and _rel(out.numpy(), g["ddpm"]) < 1e-4
+    out = samplers.ddim(x_T.clone(), eps, sched, subsample_steps=5)
+    assert _rel(out.numpy(), g["ddim"]) < 1e-4
+    out = samplers.fpndm(x_T.clone(), eps, sched, subsample_steps=10)
+    assert _rel(out.numpy(), g["fpndm"]) < 1e-4
+
+
+def test_label_sequences():
+    g = golden("label_sequences")
+    sched = schedule.base_schedule()
+    x = rnd(42, 2, 15, 32, 32)
+
+    def run(fn, **kw):
+        log = []
+
+        def eps(xx, t):
+            log.append(float(t[0]))
+            return 0.1 * xx
+        fn(x.clone(), eps, sched, **kw)
+        return np.asarray(log)
+    np.testing.assert_array_equal(run(samplers.ddpm, subsample_steps=2, noise_fn=lambda i, t: torch.zeros_like(t)),
+                                  g["labels_ddpm"])
+    np.testing.assert_array_equal(run(samplers.ddim, subsample_steps=4), g["labels_ddim"])
+    np.testing.assert_array_equal(run(samplers.fpndm, subsample_steps=4), g["labels_fpndm"])
+    np.testing.assert_array_equal(run(samplers.fpndm, subsample_steps=10), g["labels_fpndm10"])
+    lab = run(samplers.ddpm, subsample_steps=100, noise_fn=lambda i, t: torch.zeros_like(t))
+    np.testing.assert_array_equal(lab, g["labels_ddpm100"])
+    assert len(lab) == 101 and lab[-1] == 99  # the L-1 denoise-label quirk (models/__init__.py:333-335)
+
+
+@pytest.mark.slow
+def test_forward_full_size():
+    g = golden("forward_full")
+    d = Dims()
+    p = seeded_params(d, 1234)
+    x, cond = rnd(51, 1, 15, 128, 128), rnd(52, 1, 6, 128, 128)
+    o = scorenet.forward(p, d, x, torch.tensor([500]), cond=cond)
+    assert _rel(o.reshape(-1)[::60].numpy(), g["samples"]) < 5e-5
+    assert _rel(o[0, :, 0, :].numpy(), g["first_row"]) < 5e-5
