@@ -1,0 +1,173 @@
+// norm.hip -- GroupNorm as (per-channel moments) -> (per-(b,c) affine coefficients).
+//
+// The normalisation itself is never a pass of its own: consumers (conv_igemm, upfirdn2d_nhwc) apply
+// x*coef_a + coef_s (+ SiLU) while loading.  Moments are kept PER CHANNEL so that the same numbers serve
+// any grouping, including groups that straddle the two tensors of a skip-connection concat
+// (reference models/better/ncsnpp_more.py:362-364 feeds cat[h, skip] to get_act_norm).
+// HBM-bound: chan_stats reads the tensor once (4 B/element), everything else is O(B*C).
+//
+// Reference semantics: nn.GroupNorm (biased variance) via models/better/layerspp.py:473-477 (eps 1e-5),
+// :215 (eps 1e-6, affine), AdaGN get_act_norm.forward :518-549.
+#include <hip/hip_runtime.h>
+#include "../../include/evc_hip.h"
+
+namespace {
+
+// grid (nsplit, B), block 256.  Thread t owns channel quad c4 = t % C4 (C4 = C/4) and walks pixels
+// p = t / C4, + R, ... of the block's pixel range (R = 256 / C4 rows in flight); for C4 > 256 a thread
+// owns several quads.  Wave-coalesced float4 loads along C.
+__global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                         int HW, int C, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [R][C][2]
+    const int b = blockIdx.y, s = blockIdx.x;
+    const int C4 = C >> 2;
+    const int per = (HW + nsplit - 1) / nsplit;
+    const int p_begin = s * per, p_end = min(HW, p_begin + per);
+    const float* xb = x + (size_t)b * HW * C;
+    const int tid = threadIdx.x;
+    if (C4 <= 256) {
+        const int R = 256 / C4;
+        const int c4 = tid % C4, r = tid / C4;
+        float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sq = sm;
+        if (r < R) {
+            for (int p = p_begin + r; p < p_end; p += R) {
+                const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * C + 4 * c4);
+                sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+                sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+            }
+            float* d = red + ((size_t)r * C + 4 * c4) * 2;
+            d[0] = sm.x; d[1] = sq.x; d[2] = sm.y; d[3] = sq.y; d[4] = sm.z; d[5] = sq.z; d[6] = sm.w; d[7] = sq.w;
+        }
+        __syncthreads();
+        float* out = partial + ((size_t)(b * nsplit + s) * C) * 2;
+        for (int i = tid; i < 2 * C; i += 256) {
+            float acc = 0.f;
+            for (int rr = 0; rr < R; ++rr) acc += red[(size_t)rr * 2 * C + i];
+            out[i] = acc;
+        }
+    } else {
+        float* out = partial + ((size_t)(b * nsplit + s) * C) * 2;
+        for (int c4 = tid; c4 < C4; c4 += 256) {
+            float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sq = sm;
+            for (int p = p_begin; p < p_end; ++p) {
+                const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * C + 4 * c4);
+                sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+                sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+            }
+            float* d = out + 8 * c4;
+            d[0] = sm.x; d[1] = sq.x; d[2] = sm.y; d[3] = sq.y; d[4] = sm.z; d[5] = sq.z; d[6] = sm.w; d[7] = sq.w;
+        }
+    }
+}
+
+struct CoefArgs {
+    const float* part0; int nsplit0; int C0;
+    const float* part1; int nsplit1; int C1;
+    int B, HW, groups; float eps; int mode;
+    const float* gamma; const float* beta; const float* ss; int ss_ld; const int* row;
+    float* coef_a; float* coef_s;
+};
+
+// grid (groups, B), block 64: one wave reduces a group's channels x splits in double.
+__global__ __launch_bounds__(64) void gn_coeffs_kernel(CoefArgs a) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int C = a.C0 + a.C1;
+    const int cpg = C / a.groups;
+    const int c_begin = g * cpg;
+    double sm = 0.0, sq = 0.0;
+    for (int i = lane; i < cpg; i += 64) {
+        const int c = c_begin + i;
+        const float* part; int ns, cc, Cs;
+        if (c < a.C0) { part = a.part0; ns = a.nsplit0; cc = c; Cs = a.C0; }
+        else { part = a.part1; ns = a.nsplit1; cc = c - a.C0; Cs = a.C1; }
+        for (int s = 0; s < ns; ++s) {
+            const float* e = part + ((size_t)(b * ns + s) * Cs + cc) * 2;
+            sm += (double)e[0]; sq += (double)e[1];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sm += __shfl_xor(sm, off);
+        sq += __shfl_xor(sq, off);
+    }
+    const double n = (double)cpg * (double)a.HW;
+    const double mean = sm / n;
+    double var = sq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float fmean = (float)mean;
+    for (int i = lane; i < cpg; i += 64) {
+        const int c = c_begin + i;
+        float mul = 1.f, add = 0.f;
+        if (a.mode == 1) { mul = a.gamma[c]; add = a.beta[c]; }
+        else if (a.mode == 2) {
+            const float* r = a.ss + (size_t)(a.row ? a.row[b] : 0) * a.ss_ld;
+            mul = 1.f + r[c]; add = r[C + c];
+        }
+        const float ca = rstd * mul;
+        a.coef_a[(size_t)b * C + c] = ca;
+        a.coef_s[(size_t)b * C + c] = add - fmean * ca;
+    }
+}
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+    if (act == EVC_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+    if (act == EVC_ACT_RELU) return fmaxf(v, 0.0f);
+    return v;
+}
+
+__global__ void affine_act_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ ca,
+                                  const float* __restrict__ cs, int act, int HW, int C, size_t total4) {
+    const int C4 = C >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const size_t pix = i / C4;
+        const int b = (int)(pix / HW);
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        if (ca) {
+            const float4 a = *reinterpret_cast<const float4*>(ca + (size_t)b * C + 4 * c4);
+            const float4 s = *reinterpret_cast<const float4*>(cs + (size_t)b * C + 4 * c4);
+            v.x = v.x * a.x + s.x; v.y = v.y * a.y + s.y; v.z = v.z * a.z + s.z; v.w = v.w * a.w + s.w;
+        }
+        v.x = act_fn(v.x, act); v.y = act_fn(v.y, act); v.z = act_fn(v.z, act); v.w = act_fn(v.w, act);
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int evc_chan_stats_f32(const float* x, float* partial, int B, int HW, int C, int nsplit, void* stream) {
+    if (!x || !partial || B <= 0 || HW <= 0 || C <= 0 || (C & 3) || nsplit <= 0 || nsplit > HW) return EVC_EINVAL;
+    const int C4 = C >> 2;
+    const int R = C4 <= 256 ? 256 / C4 : 0;
+    const size_t lds = (size_t)R * C * 2 * sizeof(float);
+    if (lds > 64 * 1024) return EVC_EUNSUPPORTED;
+    hipLaunchKernelGGL(chan_stats_kernel, dim3(nsplit, B), dim3(256), lds, (hipStream_t)stream, x, partial, HW, C,
+                       nsplit);
+    return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
+}
+
+extern "C" int evc_gn_coeffs_f32(const float* part0, int nsplit0, int C0, const float* part1, int nsplit1, int C1,
+                                 int B, int HW, int groups, float eps, int mode, const float* gamma,
+                                 const float* beta, const float* ss, int ss_ld, const int* row, float* coef_a,
+                                 float* coef_s, void* stream) {
+    if (!part0 || C0 <= 0 || nsplit0 <= 0 || C1 < 0 || (C1 > 0 && (!part1 || nsplit1 <= 0))) return EVC_EINVAL;
+    if (B <= 0 || HW <= 0 || groups <= 0 || (C0 + C1) % groups != 0 || !coef_a || !coef_s) return EVC_EINVAL;
+    if (mode < 0 || mode > 2 || (mode == 1 && (!gamma || !beta)) || (mode == 2 && (!ss || ss_ld < 2 * (C0 + C1))))
+        return EVC_EINVAL;
+    CoefArgs a{part0, nsplit0, C0, part1, nsplit1, C1, B, HW, groups, eps, mode, gamma, beta, ss, ss_ld, row,
+               coef_a, coef_s};
+    hipLaunchKernelGGL(gn_coeffs_kernel, dim3(groups, B), dim3(64), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
+}
+
+extern "C" int evc_affine_act_nhwc_f32(const float* x, float* y, const float* coef_a, const float* coef_s, int act,
+                                       int B, int HW, int C, void* stream) {
+    if (!x || !y || B <= 0 || HW <= 0 || C <= 0 || (C & 3) || ((coef_a == nullptr) != (coef_s == nullptr)))
+        return EVC_EINVAL;
+    const size_t total4 = (size_t)B * HW * (C >> 2);
+    int grid = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+    hipLaunchKernelGGL(affine_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, coef_a, coef_s, act,
+                       HW, C, total4);
+    return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
+}

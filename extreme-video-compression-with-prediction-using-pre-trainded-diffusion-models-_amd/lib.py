@@ -1,0 +1,428 @@
+"""ctypes bindings to the two C-ABI libraries (include/evc_hip.h, include/evc_rans.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every kernel launch goes
+through the C ABI with raw pointers.  There is NO fallback path -- a missing library or a non-gfx950
+device raises ``EvcLibraryError`` so a silent eager/CPU substitute can never pass a GPU test.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_longlong, c_uint8, c_void_p
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_SO = os.path.join(HERE, "lib", "libevc_hip.so")
+RANS_SO = os.path.join(HERE, "lib", "libevc_rans.so")
+
+ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
+
+
+class EvcLibraryError(RuntimeError):
+    pass
+
+
+class EvcKernelError(RuntimeError):
+    pass
+
+
+class ConvArgs(ctypes.Structure):
+    """Mirror of ``evc_conv_args`` (include/evc_hip.h)."""
+    _fields_ = [("src0", c_void_p), ("src1", c_void_p), ("C0", c_int), ("C1", c_int),
+                ("coef_a", c_void_p), ("coef_s", c_void_p), ("act_in", c_int),
+                ("w_packed", c_void_p), ("bias", c_void_p), ("res", c_void_p), ("ld_res", c_int),
+                ("out_scale", c_float), ("act_out", c_int),
+                ("out", c_void_p), ("ld_out", c_int),
+                ("B", c_int), ("H", c_int), ("W", c_int), ("Co", c_int), ("KH", c_int), ("KW", c_int),
+                ("splits", c_int)]
+
+
+# name -> (restype, argtypes); exactly the symbols declared in include/evc_hip.h
+HIP_SYMBOLS = {
+    "evc_version": (c_char_p, []),
+    "evc_arch": (c_char_p, []),
+    "evc_device_ok": (c_int, []),
+    "evc_upfirdn2d_f32": (c_int, [c_void_p, c_void_p, POINTER(c_float)] + [c_int] * 13 + [c_void_p]),
+    "evc_upfirdn2d_nhwc_f32": (c_int, [c_void_p, c_void_p, POINTER(c_float)] + [c_int] * 10 +
+                               [c_void_p, c_void_p, c_int, c_void_p]),
+    "evc_pack_nchw_to_nhwc_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                          c_void_p]),
+    "evc_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "evc_chan_stats_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "evc_gn_coeffs_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                  c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]),
+    "evc_affine_act_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                        c_void_p]),
+    "evc_conv_co_pad": (c_int, [c_int]),
+    "evc_conv_packed_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
+    "evc_conv_pack_weights_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "evc_conv_choose_splits": (c_int, [POINTER(ConvArgs)]),
+    "evc_conv_workspace_bytes": (c_longlong, [POINTER(ConvArgs)]),
+    "evc_conv2d_nhwc_f32": (c_int, [POINTER(ConvArgs), c_void_p, c_void_p]),
+    "evc_attention_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                  c_float, c_void_p]),
+    "evc_ddpm_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong] + [c_float] * 5 + [c_int, c_void_p]),
+    "evc_ddim_step_f32": (c_int, [c_void_p, c_void_p, c_longlong] + [c_float] * 4 + [c_int, c_void_p]),
+    "evc_axpy_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_void_p]),
+    "evc_pndm_transfer_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_int,
+                                      c_void_p]),
+    "evc_lincomb4_f32": (c_int, [c_void_p] * 5 + [c_longlong] + [c_float] * 4 + [c_void_p]),
+    "evc_scale_clamp_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_float, c_int, c_float, c_float,
+                                    c_void_p]),
+    "evc_gate_residual_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]),
+    "evc_elic_gather_params_f32": (c_int, [c_void_p] + [c_int] * 8 + [c_void_p, c_int, c_void_p, c_void_p,
+                                                                       c_void_p]),
+    "evc_elic_scatter_symbols_f32": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+}
+
+RANS_SYMBOLS = {
+    "evc_rans_version": (c_char_p, []),
+    "evc_rans_max_encoded_bytes": (c_longlong, [c_longlong]),
+    "evc_rans_encode_with_indexes": (c_longlong, [POINTER(c_int32), POINTER(c_int32), c_longlong, POINTER(c_int32),
+                                                  c_int, POINTER(c_int32), POINTER(c_int32), c_int,
+                                                  POINTER(c_uint8), c_longlong]),
+    "evc_rans_decode_with_indexes": (c_int, [POINTER(c_uint8), c_longlong, POINTER(c_int32), c_longlong,
+                                             POINTER(c_int32), c_int, POINTER(c_int32), POINTER(c_int32), c_int,
+                                             POINTER(c_int32)]),
+    "evc_pmf_to_quantized_cdf": (c_int, [POINTER(c_float), c_int, c_int, POINTER(c_int32)]),
+}
+
+_hip = None
+_rans = None
+
+
+def _load(path, symbols, what):
+    if not os.path.exists(path):
+        raise EvcLibraryError(f"{what} not built: {path} is missing. Run `python -c \"import __graft_entry__ as g; "
+                              f"g.build()\"` (needs hipcc / g++). There is no fallback path.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in symbols.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise EvcLibraryError(f"{path} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def hip_lib(require_device=True):
+    """The HIP kernel library.  ``require_device=False`` is only for symbol/export checks on CPU boxes."""
+    global _hip
+    if _hip is None:
+        _hip = _load(HIP_SO, HIP_SYMBOLS, "libevc_hip.so")
+    if require_device:
+        if not torch.cuda.is_available():
+            raise EvcLibraryError("no HIP device visible: the evc_amd compute path is gfx950-only (no CPU fallback)")
+        if not getattr(hip_lib, "_checked", False):
+            if _hip.evc_device_ok() != 1:
+                raise EvcLibraryError("current HIP device is not gfx950 (MI355X); libevc_hip.so has no code for it")
+            hip_lib._checked = True
+    return _hip
+
+
+def rans_lib():
+    global _rans
+    if _rans is None:
+        _rans = _load(RANS_SO, RANS_SYMBOLS, "libevc_rans.so")
+    return _rans
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise EvcKernelError(f"{name} failed with code {rc} "
+                             "(-1 invalid argument, -2 unsupported, -3 launch failure)")
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-contiguous tensor required"
+    return c_void_p(t.data_ptr())
+
+
+def fptr(t, dtype=torch.float32):
+    assert t is None or t.dtype == dtype, (t.dtype, dtype)
+    return ptr(t)
+
+
+# ----------------------------------------------------------------------------------------------
+# thin, shape-checked wrappers (one per C entry point that the host code uses)
+# ----------------------------------------------------------------------------------------------
+
+def upfirdn2d_nchw(x, kernel, up=1, down=1, pad=(0, 0)):
+    """Drop-in for reference ``upfirdn2d(input, kernel, up, down, pad)`` (models/better/op/upfirdn2d.py:13)."""
+    L = hip_lib()
+    assert x.dim() == 4 and x.dtype == torch.float32
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    k = np.ascontiguousarray(np.asarray(kernel.detach().cpu() if torch.is_tensor(kernel) else kernel,
+                                        dtype=np.float32))
+    kh, kw = k.shape
+    oh = (h * up + pad[0] + pad[1] - kh) // down + 1
+    ow = (w * up + pad[0] + pad[1] - kw) // down + 1
+    out = torch.empty((n, c, oh, ow), device=x.device, dtype=torch.float32)
+    _check(L.evc_upfirdn2d_f32(fptr(x), fptr(out), k.ctypes.data_as(POINTER(c_float)), n * c, h, w, kh, kw, up, up,
+                               down, down, pad[0], pad[1], pad[0], pad[1], stream_ptr()), "evc_upfirdn2d_f32")
+    return out
+
+
+def upfirdn2d_nhwc(x, kernel, up, down, pad, coef=None, act=ACT_NONE, out=None):
+    L = hip_lib()
+    B, H, W, C = x.shape
+    k = np.ascontiguousarray(np.asarray(kernel, dtype=np.float32))
+    kh, kw = k.shape
+    oh = (H * up + pad[0] + pad[1] - kh) // down + 1
+    ow = (W * up + pad[0] + pad[1] - kw) // down + 1
+    if out is None:
+        out = torch.empty((B, oh, ow, C), device=x.device, dtype=torch.float32)
+    ca, cs = coef if coef is not None else (None, None)
+    _check(L.evc_upfirdn2d_nhwc_f32(fptr(x), fptr(out), k.ctypes.data_as(POINTER(c_float)), B, H, W, C, kh, kw, up,
+                                    down, pad[0], pad[1], fptr(ca), fptr(cs), act, stream_ptr()),
+           "evc_upfirdn2d_nhwc_f32")
+    return out
+
+
+def pack_nchw_to_nhwc(x0, x1, cpad, out=None):
+    L = hip_lib()
+    B, C0, H, W = x0.shape
+    C1 = 0 if x1 is None else x1.shape[1]
+    if out is None:
+        out = torch.empty((B, H, W, cpad), device=x0.device, dtype=torch.float32)
+    _check(L.evc_pack_nchw_to_nhwc_f32(fptr(x0.contiguous()), C0, fptr(None if x1 is None else x1.contiguous()), C1,
+                                       fptr(out), cpad, B, H, W, stream_ptr()), "evc_pack_nchw_to_nhwc_f32")
+    return out
+
+
+def nhwc_to_nchw(x, C, out=None):
+    L = hip_lib()
+    B, H, W, ld = x.shape
+    if out is None:
+        out = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
+    _check(L.evc_nhwc_to_nchw_f32(fptr(x), ld, fptr(out), B, C, H, W, stream_ptr()), "evc_nhwc_to_nchw_f32")
+    return out
+
+
+def stats_splits(B, HW):
+    """Number of pixel ranges per image for evc_chan_stats_f32: enough blocks to fill the chip while every
+    block still streams >= 64 pixels."""
+    n = max(1, min(HW // 64, (1024 + B - 1) // B))
+    return n
+
+
+def chan_stats(x):
+    """x: (B, H, W, C) -> partial moments (B, nsplit, C, 2)."""
+    L = hip_lib()
+    B, H, W, C = x.shape
+    ns = stats_splits(B, H * W)
+    part = torch.empty((B, ns, C, 2), device=x.device, dtype=torch.float32)
+    _check(L.evc_chan_stats_f32(fptr(x), fptr(part), B, H * W, C, ns, stream_ptr()), "evc_chan_stats_f32")
+    return part
+
+
+def gn_coeffs(parts, HW, groups, eps, mode=0, gamma=None, beta=None, ss=None, row=None):
+    """parts: one or two partial-moment tensors (virtual concat). Returns (coef_a, coef_s), each (B, C)."""
+    L = hip_lib()
+    p0 = parts[0]
+    p1 = parts[1] if len(parts) > 1 else None
+    B, ns0, C0, _ = p0.shape
+    ns1, C1 = (p1.shape[1], p1.shape[2]) if p1 is not None else (0, 0)
+    C = C0 + C1
+    ca = torch.empty((B, C), device=p0.device, dtype=torch.float32)
+    cs = torch.empty((B, C), device=p0.device, dtype=torch.float32)
+    ss_ld = 0 if ss is None else ss.stride(0)
+    _check(L.evc_gn_coeffs_f32(fptr(p0), ns0, C0, fptr(p1), ns1, C1, B, HW, groups, eps, mode, fptr(gamma),
+                               fptr(beta), c_void_p(ss.data_ptr()) if ss is not None else None, ss_ld,
+                               fptr(row, torch.int32), fptr(ca), fptr(cs), stream_ptr()), "evc_gn_coeffs_f32")
+    return ca, cs
+
+
+def affine_act(x, coef, act, out=None):
+    L = hip_lib()
+    B, H, W, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    ca, cs = coef if coef is not None else (None, None)
+    _check(L.evc_affine_act_nhwc_f32(fptr(x), fptr(out), fptr(ca), fptr(cs), act, B, H * W, C, stream_ptr()),
+           "evc_affine_act_nhwc_f32")
+    return out
+
+
+def conv_pack_weights(w):
+    """w: (Co, Ci, KH, KW) device float32 with Ci % 16 == 0 -> packed flat tensor."""
+    L = hip_lib()
+    w = w.contiguous()
+    Co, Ci, KH, KW = w.shape
+    n = L.evc_conv_packed_floats(Co, Ci, KH, KW)
+    packed = torch.empty((n,), device=w.device, dtype=torch.float32)
+    _check(L.evc_conv_pack_weights_f32(fptr(w), fptr(packed), Co, Ci, KH, KW, stream_ptr()),
+           "evc_conv_pack_weights_f32")
+    return packed
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """Grow-only split-K workspace per device (stream-ordered reuse on the current stream)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    cur = _ws_cache.get(key)
+    if cur is None or cur.numel() * 4 < nbytes:
+        cur = torch.empty(((nbytes + 3) // 4,), device=device, dtype=torch.float32)
+        _ws_cache[key] = cur
+    return cur
+
+
+def conv2d_nhwc(src0, w_packed, Co, KH, KW, bias=None, src1=None, coef=None, act_in=ACT_NONE, res=None,
+                out_scale=1.0, act_out=ACT_NONE, out=None, splits=0):
+    """out = act_out((conv(act_in(cat[src0,src1]*a+s), w) + bias + res) * out_scale); tensors are NHWC."""
+    L = hip_lib()
+    B, H, W, C0 = src0.shape
+    C1 = 0 if src1 is None else src1.shape[3]
+    if out is None:
+        out = torch.empty((B, H, W, Co), device=src0.device, dtype=torch.float32)
+    ca, cs = coef if coef is not None else (None, None)
+    a = ConvArgs(ptr(src0), ptr(src1), C0, C1, ptr(ca), ptr(cs), act_in, ptr(w_packed), ptr(bias), ptr(res),
+                 0 if res is None else res.shape[-1], float(out_scale), act_out, ptr(out), out.shape[-1],
+                 B, H, W, Co, KH, KW, splits)
+    nbytes = L.evc_conv_workspace_bytes(ctypes.byref(a))
+    if nbytes < 0:
+        raise EvcKernelError(f"evc_conv_workspace_bytes rejected the arguments ({nbytes})")
+    ws = _workspace(nbytes, src0.device) if nbytes > 0 else None
+    _check(L.evc_conv2d_nhwc_f32(ctypes.byref(a), ptr(ws), stream_ptr()), "evc_conv2d_nhwc_f32")
+    return out
+
+
+def attention(qkv, C, heads, out=None):
+    """qkv: (B, N, 3C) with q | k | v concatenated along channels; returns (B, N, C)."""
+    L = hip_lib()
+    B, N, ld = qkv.shape
+    D = C // heads
+    if out is None:
+        out = torch.empty((B, N, C), device=qkv.device, dtype=torch.float32)
+    base = qkv.data_ptr()
+    _check(L.evc_attention_f32(c_void_p(base), c_void_p(base + 4 * C), c_void_p(base + 8 * C), ld, fptr(out), C, B,
+                               heads, N, D, float(int(D) ** (-0.5)), stream_ptr()), "evc_attention_f32")
+    return out
+
+
+def ddpm_step(x, e, noise, k1, k2, c1, c2, sigma, clip):
+    _check(hip_lib().evc_ddpm_step_f32(fptr(x), fptr(e), fptr(noise), x.numel(), k1, k2, c1, c2, sigma, int(clip),
+                                       stream_ptr()), "evc_ddpm_step_f32")
+
+
+def ddim_step(x, e, k1, k2, c1, c2, clip):
+    _check(hip_lib().evc_ddim_step_f32(fptr(x), fptr(e), x.numel(), k1, k2, c1, c2, int(clip), stream_ptr()),
+           "evc_ddim_step_f32")
+
+
+def axpy(x, e, alpha, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    _check(hip_lib().evc_axpy_f32(fptr(x), fptr(e), fptr(out), x.numel(), alpha, stream_ptr()), "evc_axpy_f32")
+    return out
+
+
+def pndm_transfer(x, e, d, cx, ce, clip, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    _check(hip_lib().evc_pndm_transfer_f32(fptr(x), fptr(e), fptr(out), x.numel(), d, cx, ce, int(clip),
+                                           stream_ptr()), "evc_pndm_transfer_f32")
+    return out
+
+
+def lincomb4(es, ws, out=None):
+    es = list(es) + [None] * (4 - len(es))
+    ws = list(ws) + [0.0] * (4 - len(ws))
+    if out is None:
+        out = torch.empty_like(es[0])
+    _check(hip_lib().evc_lincomb4_f32(fptr(es[0]), fptr(es[1]), fptr(es[2]), fptr(es[3]), fptr(out), out.numel(),
+                                      *[float(w) for w in ws], stream_ptr()), "evc_lincomb4_f32")
+    return out
+
+
+def scale_clamp(x, mul, add, clamp=None, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    lo, hi = clamp if clamp is not None else (0.0, 0.0)
+    _check(hip_lib().evc_scale_clamp_f32(fptr(x), fptr(out), x.numel(), mul, add, int(clamp is not None), lo, hi,
+                                         stream_ptr()), "evc_scale_clamp_f32")
+    return out
+
+
+def gate_residual(a, b, x, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    _check(hip_lib().evc_gate_residual_f32(fptr(a), fptr(b), fptr(x), fptr(out), x.numel(), stream_ptr()),
+           "evc_gate_residual_f32")
+    return out
+
+
+def elic_gather_params(ms, mean_off, scale_off, C, parity, scale_table):
+    """ms: (B, H, W, ld) -> (idx int32 (B, C, H, W/2), means float32 (B, C, H, W/2))."""
+    B, H, W, ld = ms.shape
+    idx = torch.empty((B, C, H, W // 2), device=ms.device, dtype=torch.int32)
+    means = torch.empty((B, C, H, W // 2), device=ms.device, dtype=torch.float32)
+    _check(hip_lib().evc_elic_gather_params_f32(fptr(ms), ld, mean_off, scale_off, C, B, H, W, parity,
+                                                fptr(scale_table), scale_table.numel(), fptr(idx, torch.int32),
+                                                fptr(means), stream_ptr()), "evc_elic_gather_params_f32")
+    return idx, means
+
+
+def elic_scatter_symbols(symbols, means, y_hat, c0, parity):
+    B, C, H, Wh = symbols.shape
+    _check(hip_lib().evc_elic_scatter_symbols_f32(fptr(symbols, torch.int32), fptr(means), fptr(y_hat),
+                                                  y_hat.shape[-1], c0, C, B, H, 2 * Wh, parity, stream_ptr()),
+           "evc_elic_scatter_symbols_f32")
+
+
+# ---- host rANS -------------------------------------------------------------------------------
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def rans_encode(symbols, indexes, cdfs, cdf_sizes, offsets):
+    """-> bytes.  Arguments are int arrays; ``cdfs`` is (n_cdfs, ld)."""
+    L = rans_lib()
+    s, i, c, z, o = _i32(symbols).ravel(), _i32(indexes).ravel(), _i32(cdfs), _i32(cdf_sizes).ravel(), _i32(offsets).ravel()
+    cap = L.evc_rans_max_encoded_bytes(s.size)
+    out = np.empty(cap, dtype=np.uint8)
+    P32, P8 = POINTER(c_int32), POINTER(c_uint8)
+    n = L.evc_rans_encode_with_indexes(s.ctypes.data_as(P32), i.ctypes.data_as(P32), s.size, c.ctypes.data_as(P32),
+                                       c.shape[1], z.ctypes.data_as(P32), o.ctypes.data_as(P32), c.shape[0],
+                                       out.ctypes.data_as(P8), cap)
+    if n < 0:
+        raise EvcKernelError(f"evc_rans_encode_with_indexes failed ({n})")
+    return out[:n].tobytes()
+
+
+def rans_decode(data, indexes, cdfs, cdf_sizes, offsets):
+    """-> int32 array of len(indexes) symbols."""
+    L = rans_lib()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    i, c, z, o = _i32(indexes).ravel(), _i32(cdfs), _i32(cdf_sizes).ravel(), _i32(offsets).ravel()
+    out = np.empty(i.size, dtype=np.int32)
+    P32, P8 = POINTER(c_int32), POINTER(c_uint8)
+    rc = L.evc_rans_decode_with_indexes(buf.ctypes.data_as(P8), buf.size, i.ctypes.data_as(P32), i.size,
+                                        c.ctypes.data_as(P32), c.shape[1], z.ctypes.data_as(P32),
+                                        o.ctypes.data_as(P32), c.shape[0], out.ctypes.data_as(P32))
+    if rc != 0:
+        raise EvcKernelError(f"evc_rans_decode_with_indexes failed ({rc})")
+    return out
+
+
+def pmf_to_quantized_cdf(pmf, precision=16):
+    L = rans_lib()
+    p = np.ascontiguousarray(pmf, dtype=np.float32)
+    out = np.empty(p.size + 1, dtype=np.int32)
+    rc = L.evc_pmf_to_quantized_cdf(p.ctypes.data_as(POINTER(c_float)), p.size, precision,
+                                    out.ctypes.data_as(POINTER(c_int32)))
+    if rc != 0:
+        raise EvcKernelError(f"evc_pmf_to_quantized_cdf failed ({rc})")
+    return out

@@ -1,0 +1,174 @@
+"""DDPM / DDIM / F-PNDM sampling loops on MI355X.
+
+Same call surface as the reference samplers (models/__init__.py:39-100, 103-204, 207-342):
+``sampler(x_mod, scorenet, cond=None, final_only=..., denoise=..., subsample_steps=..., clip_before=...,
+same_noise=..., noise_val=..., **kw) -> Tensor (1, B, C, H, W)`` and they read
+``scorenet.alphas / alphas_prev / betas`` (and ``.module`` if wrapped).  The per-step scalar coefficients
+are formed on the host in float32 with exactly the reference's expressions; the tensor update of each
+step is ONE fused elementwise kernel (evc_ddpm_step_f32 / evc_ddim_step_f32 / evc_pndm_transfer_f32)
+instead of the reference's ~8 separate passes, and the 10 discarded logging norms
+(models/__init__.py:297-303) are not computed.
+
+Noise: ``noise_fn(i, x)`` injects the Gaussian the reference would draw with ``torch.randn_like`` after
+step ``i`` (parity tests); otherwise it is drawn on-device from ``generator`` (Philox).
+"""
+import torch
+
+from . import lib as L
+
+
+def _net(scorenet):
+    return scorenet.module if hasattr(scorenet, "module") else scorenet
+
+
+def _eps(net, x, label, cond):
+    if hasattr(net, "forward_label"):
+        return net.forward_label(x, label, cond)
+    labels = torch.full((x.shape[0],), label, device=x.device,
+                        dtype=torch.long if float(label).is_integer() else torch.float32)
+    return net(x, labels, cond=cond)
+
+
+def _subsample(net, subsample_steps):
+    """models/__init__.py:231-239 (float32 CPU arithmetic, incl. the lossy 1 - a/a_prev)."""
+    alphas, alphas_prev, betas = net.alphas.cpu(), net.alphas_prev.cpu(), net.betas.cpu()
+    steps = torch.arange(len(betas))
+    if subsample_steps is not None and subsample_steps < len(alphas):
+        skip = len(alphas) // subsample_steps
+        steps = torch.tensor(list(range(0, len(alphas), skip)))
+        alphas = alphas.index_select(0, steps)
+        alphas_prev = torch.cat([alphas[1:], torch.tensor([1.0]).to(alphas)])
+        betas = 1.0 - torch.div(alphas, alphas_prev)
+    return steps, alphas, alphas_prev, betas
+
+
+def _prepare(net, labels):
+    if hasattr(net, "prepare_labels"):
+        net.prepare_labels(labels)
+
+
+@torch.no_grad()
+def ddpm_sampler(x_mod, scorenet, cond=None, just_beta=False, final_only=False, denoise=True,
+                 subsample_steps=None, same_noise=False, noise_val=None, frac_steps=None, verbose=False,
+                 log=False, clip_before=True, t_min=-1, gamma=False, noise_fn=None, generator=None, **kwargs):
+    if gamma or frac_steps is not None or t_min > 0:
+        raise NotImplementedError("gamma / frac_steps / t_min>0 are unreachable from the reference CLI")
+    net = _net(scorenet)
+    steps, alphas, alphas_prev, betas = _subsample(net, subsample_steps)
+    L_ = len(steps)
+    _prepare(net, [int(s) for s in steps] + ([L_ - 1] if denoise else []))
+    x = x_mod.detach().to(torch.float32).clone().contiguous()
+    if same_noise and noise_val is None:
+        noise_val = x.clone()
+    images = []
+    for i, step in enumerate(steps):
+        c_beta, c_alpha, c_alpha_prev = betas[i], alphas[i], alphas_prev[i]
+        e = _eps(net, x, int(step), cond)
+        k1 = float(1 / c_alpha.sqrt())
+        k2 = float((1 - c_alpha).sqrt())
+        c1 = float(c_alpha_prev.sqrt() * c_beta / (1 - c_alpha))
+        c2 = float((1 - c_beta).sqrt() * (1 - c_alpha_prev) / (1 - c_alpha))
+        noise, sigma = None, 0.0
+        if i + 1 != L_:
+            if same_noise:
+                noise = noise_val
+            elif noise_fn is not None:
+                noise = noise_fn(i, x).to(x.device, torch.float32).contiguous()
+            else:
+                noise = torch.randn(x.shape, device=x.device, dtype=torch.float32, generator=generator)
+            sigma = float(c_beta.sqrt()) if just_beta else float(((1 - c_alpha_prev) / (1 - c_alpha) * c_beta).sqrt())
+        L.ddpm_step(x, e, noise, k1, k2, c1, c2, sigma, clip_before)
+        if not final_only:
+            images.append(x.to("cpu"))
+    if denoise:
+        e = _eps(net, x, L_ - 1, cond)   # label is the COUNT index L-1 (models/__init__.py:333-335)
+        x = L.axpy(x, e, -float((1 - alphas[-1]).sqrt()))
+        if not final_only:
+            images.append(x.to("cpu"))
+    return x.unsqueeze(0) if final_only else torch.stack(images)
+
+
+@torch.no_grad()
+def ddim_sampler(x_mod, scorenet, cond=None, final_only=False, denoise=True, subsample_steps=None, verbose=False,
+                 log=True, clip_before=True, t_min=-1, gamma=False, **kwargs):
+    if gamma or t_min > 0:
+        raise NotImplementedError("gamma / t_min>0 are unreachable from the reference CLI")
+    net = _net(scorenet)
+    steps, alphas, alphas_prev, betas = _subsample(net, subsample_steps)
+    L_ = len(steps)
+    _prepare(net, [int(s) for s in steps] + ([L_ - 1] if denoise else []))
+    x = x_mod.detach().to(torch.float32).clone().contiguous()
+    images = []
+    for i, step in enumerate(steps):
+        c_alpha, c_alpha_prev = alphas[i], alphas_prev[i]
+        e = _eps(net, x, int(step), cond)
+        L.ddim_step(x, e, float(1 / c_alpha.sqrt()), float((1 - c_alpha).sqrt()), float(c_alpha_prev.sqrt()),
+                    float((1 - c_alpha_prev).sqrt()), clip_before)
+        if not final_only:
+            images.append(x.to("cpu"))
+    if denoise:
+        e = _eps(net, x, L_ - 1, cond)
+        x = L.axpy(x, e, -float((1 - alphas[-1]).sqrt()))
+        if not final_only:
+            images.append(x.to("cpu"))
+    return x.unsqueeze(0) if final_only else torch.stack(images)
+
+
+def _transfer(x, t, t_next, e, alphas_cump, clip_before):
+    """models/pndm.py:19-33 with the scalar coefficients formed on the host."""
+    at = alphas_cump[int(t) + 1]          # .long() truncates toward zero, as int() does
+    an = alphas_cump[int(t_next) + 1]
+    d = float(an - at)
+    cx = float(1 / (at.sqrt() * (at.sqrt() + an.sqrt())))
+    ce = float(1 / (at.sqrt() * (((1 - an) * at).sqrt() + ((1 - at) * an).sqrt())))
+    return L.pndm_transfer(x, e, d, cx, ce, clip_before)
+
+
+@torch.no_grad()
+def FPNDM_sampler(x_mod, scorenet, cond=None, final_only=False, denoise=True, subsample_steps=None, verbose=False,
+                  log=True, clip_before=True, t_min=-1, gamma=False, **kwargs):
+    """FPNDM_sampler + pndm.gen_order_4 / runge_kutta (models/__init__.py:39-100, models/pndm.py:3-52):
+    3 Runge-Kutta warm-up iterations (4 evaluations each) then 4-term Adams-Bashforth; no denoise call."""
+    net = _net(scorenet)
+    alphas_old = net.alphas.cpu().flip(0)
+    skip = len(alphas_old) // subsample_steps
+    steps = list(range(0, len(alphas_old), skip))
+    steps_next = [-1] + steps[:-1]
+    labels = set()
+    for t, tn in zip(steps, steps_next):
+        labels.update([float(t), (t + tn) / 2, float(tn)])
+    _prepare(net, sorted(labels))
+    x = x_mod.detach().to(torch.float32).clone().contiguous()
+    ets, images = [], []
+    for t, tn in zip(steps, steps_next):
+        if len(ets) > 2:
+            ets.append(_eps(net, x, t, cond))
+            e = L.lincomb4([ets[-1], ets[-2], ets[-3], ets[-4]], [55 / 24, -59 / 24, 37 / 24, -9 / 24])
+            ets = ets[-4:]   # the reference keeps the whole history (never trimmed); only 4 are ever read
+        else:
+            tm = (t + tn) / 2
+            e1 = _eps(net, x, t, cond)
+            ets.append(e1)
+            x2 = _transfer(x, t, tm, e1, alphas_old, clip_before)
+            e2 = _eps(net, x2, tm, cond)
+            x3 = _transfer(x, t, tm, e2, alphas_old, clip_before)
+            e3 = _eps(net, x3, tm, cond)
+            x4 = _transfer(x, t, tn, e3, alphas_old, clip_before)
+            e4 = _eps(net, x4, tn, cond)
+            e = L.lincomb4([e1, e2, e3, e4], [1 / 6, 2 / 6, 2 / 6, 1 / 6])
+        x = _transfer(x, t, tn, e, alphas_old, clip_before)
+        if not final_only:
+            images.append(x.to("cpu"))
+    return x.unsqueeze(0) if final_only else torch.stack(images)
+
+
+def get_sampler(version):
+    """city_sender.py:248-254 (+ FPNDM for BASELINE config 5)."""
+    version = version.upper()
+    if version == "DDPM":
+        return ddpm_sampler
+    if version == "DDIM":
+        return ddim_sampler
+    if version in ("FPNDM", "PNDM"):
+        return FPNDM_sampler
+    raise ValueError(f"unknown sampler {version}")

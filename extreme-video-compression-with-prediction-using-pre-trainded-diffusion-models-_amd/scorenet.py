@@ -1,0 +1,332 @@
+"""Score network (NCSN++ "unetmore") on MI355X.
+
+Host-side mirror of the reference's ``UNetMore_DDPM`` / ``NCSNpp`` (models/better/ncsnpp_more.py:32-392,
+721-770): same constructor input (a config namespace), same ``state_dict`` key names
+(``unet.all_modules.<i>...``), same call signature ``net(x, labels, cond=None, cond_mask=None) -> eps`` with
+NCHW float32 tensors, same ``alphas / alphas_prev / betas`` buffers the samplers read
+(models/__init__.py:223).  Everything between the NCHW boundary tensors runs in NHWC through the HIP
+kernels of libevc_hip.so:
+
+* 3x3 / 1x1 convolutions, NIN and the Linear layers -> ``evc_conv2d_nhwc_f32`` (implicit GEMM on the f32
+  matrix cores) with the preceding GroupNorm affine + SiLU fused into its operand load, the skip
+  concat read in place (two sources), and bias + residual + 1/sqrt(2) fused into its epilogue;
+* GroupNorm -> per-channel moments (``evc_chan_stats_f32``, computed once per tensor and reused for every
+  grouping it takes part in) + ``evc_gn_coeffs_f32``;
+* FIR up/down sampling -> ``evc_upfirdn2d_nhwc_f32`` with the AdaGN + SiLU of the h-branch fused on load;
+* q/k/v NINs as ONE 1x1 conv (Co = 3C) feeding ``evc_attention_f32``;
+* the time-embedding MLP and all 70 AdaGN ``Dense_0`` projections depend only on the label, so they are
+  evaluated once per distinct label into a table row -- 72 GEMVs per forward become 0.
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+FIR_K = np.outer([1, 3, 3, 1], [1, 3, 3, 1]).astype(np.float32)
+FIR_K /= FIR_K.sum()
+INV_SQRT2 = float(np.float32(1.0) / np.sqrt(np.float32(2.0)))
+
+
+def num_groups(ch):
+    """reference models/better/layerspp.py:473-476."""
+    g = min(ch // 4, 32)
+    while ch % g != 0:
+        g -= 1
+    return g
+
+
+def dims_from_config(config):
+    m, d = config.model, config.data
+    return SimpleNamespace(ngf=m.ngf, ch_mult=list(m.ch_mult), num_res_blocks=m.num_res_blocks,
+                           attn_resolutions=list(m.attn_resolutions), n_head_channels=m.n_head_channels,
+                           image_size=d.image_size, channels=d.channels, num_frames=d.num_frames,
+                           num_frames_cond=d.num_frames_cond + getattr(d, "num_frames_future", 0),
+                           sigma_begin=getattr(m, "sigma_begin", 0.02), sigma_end=getattr(m, "sigma_end", 1e-4),
+                           num_classes=getattr(m, "num_classes", 1000))
+
+
+def build_program(d):
+    """Module records in the order of NCSNpp.__init__ (ncsnpp_more.py:70-247)."""
+    mods = [dict(kind="linear"), dict(kind="linear")]
+    res = [d.image_size // (2 ** i) for i in range(len(d.ch_mult))]
+    mods.append(dict(kind="conv_in", cin=d.channels * (d.num_frames + d.num_frames_cond), cout=d.ngf))
+    hs_c = [d.ngf]
+    in_ch = d.ngf
+    for lvl, mult in enumerate(d.ch_mult):
+        for _ in range(d.num_res_blocks):
+            mods.append(dict(kind="res", cin=in_ch, cout=d.ngf * mult, up=False, down=False))
+            in_ch = d.ngf * mult
+            if res[lvl] in d.attn_resolutions:
+                mods.append(dict(kind="attn", ch=in_ch))
+            hs_c.append(in_ch)
+        if lvl != len(d.ch_mult) - 1:
+            mods.append(dict(kind="res", cin=in_ch, cout=in_ch, up=False, down=True))
+            hs_c.append(in_ch)
+    in_ch = hs_c[-1]
+    mods.append(dict(kind="res", cin=in_ch, cout=in_ch, up=False, down=False))
+    mods.append(dict(kind="attn", ch=in_ch))
+    mods.append(dict(kind="res", cin=in_ch, cout=in_ch, up=False, down=False))
+    for lvl in reversed(range(len(d.ch_mult))):
+        for _ in range(d.num_res_blocks + 1):
+            skip = hs_c.pop()
+            mods.append(dict(kind="res", cin=in_ch + skip, cout=d.ngf * d.ch_mult[lvl], up=False, down=False,
+                             split=(in_ch, skip)))
+            in_ch = d.ngf * d.ch_mult[lvl]
+        if res[lvl] in d.attn_resolutions:
+            mods.append(dict(kind="attn", ch=in_ch))
+        if lvl != 0:
+            mods.append(dict(kind="res", cin=in_ch, cout=in_ch, up=True, down=False))
+    assert not hs_c
+    mods.append(dict(kind="norm", ch=in_ch))
+    mods.append(dict(kind="conv_out", cin=in_ch, cout=d.channels * d.num_frames))
+    return mods
+
+
+class _Act:
+    """An NHWC activation with lazily computed, cached per-channel moments."""
+    __slots__ = ("t", "_stats")
+
+    def __init__(self, t):
+        self.t = t
+        self._stats = None
+
+    def stats(self):
+        if self._stats is None:
+            self._stats = L.chan_stats(self.t)
+        return self._stats
+
+
+def _pad16(c):
+    return (c + 15) // 16 * 16
+
+
+class ScoreNet:
+    """HIP implementation of ``UNetMore_DDPM`` (eval mode, dropout 0, spade/cond_emb/noise_in_cond off)."""
+
+    def __init__(self, config, state_dict, device="cuda", prefix=""):
+        L.hip_lib()   # fail loudly before touching anything else
+        self.config = config
+        self.device = torch.device(device)
+        self.d = dims_from_config(config)
+        self.type = getattr(config.model, "type", "v1")
+        m = config.model
+        if getattr(m, "spade", False) or getattr(m, "cond_emb", False) or getattr(m, "noise_in_cond", False) or \
+                getattr(m, "output_all_frames", False) or m.arch != "unetmore":
+            raise NotImplementedError("only the arch=unetmore / concat-conditioning configuration of "
+                                      "configs/mine.yml is on the hot path (SURVEY.md section 2)")
+        # schedule buffers exactly as ncsnpp_more.py:735-739 builds them (CPU float32; the samplers index them)
+        if getattr(m, "sigma_dist", "linear") != "linear":
+            raise NotImplementedError("sigma_dist != linear")
+        self.betas = torch.linspace(self.d.sigma_begin, self.d.sigma_end, self.d.num_classes)
+        self.alphas = torch.cumprod(1 - self.betas.flip(0), 0).flip(0)
+        self.alphas_prev = torch.cat([self.alphas[1:], torch.tensor([1.0]).to(self.alphas)])
+        self.program = build_program(self.d)
+        self._load(state_dict, prefix + "unet.all_modules.")
+        self._rows = {}          # label value -> row of the AdaGN table
+        self._row_tensors = {}   # (row, B) -> int32 device tensor
+        self._table = torch.zeros((0, self.ss_total), device=self.device, dtype=torch.float32)
+
+    # ------------------------------------------------------------------------------------------
+    def _dev(self, t):
+        return t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _pack_conv(self, w, pad_ci=None):
+        w = self._dev(w)
+        if pad_ci is not None and pad_ci != w.shape[1]:
+            wp = torch.zeros((w.shape[0], pad_ci, w.shape[2], w.shape[3]), device=self.device)
+            wp[:, :w.shape[1]] = w
+            w = wp
+        return L.conv_pack_weights(w)
+
+    def _load(self, sd, pre):
+        g = lambda name: sd[name]
+        self.w = {}
+        dense_w, dense_b = [], []
+        off = 0
+        for i, m in enumerate(self.program):
+            n = pre + str(i)
+            k = m["kind"]
+            if k == "linear":
+                w = g(n + ".weight")
+                self.w[i] = dict(w=self._pack_conv(w[:, :, None, None]), b=self._dev(g(n + ".bias")),
+                                 co=w.shape[0])
+            elif k in ("conv_in", "conv_out"):
+                w = g(n + ".weight")
+                self.w[i] = dict(w=self._pack_conv(w, _pad16(w.shape[1])), b=self._dev(g(n + ".bias")),
+                                 co=w.shape[0], cin_pad=_pad16(w.shape[1]))
+            elif k == "res":
+                e = dict()
+                for j, key in ((0, "actnorm0"), (1, "actnorm1")):
+                    dw, db = g(f"{n}.{key}.Dense_0.weight"), g(f"{n}.{key}.Dense_0.bias")
+                    dense_w.append(dw); dense_b.append(db)
+                    e[f"ss{j}"] = (off, dw.shape[0] // 2)
+                    off += dw.shape[0]
+                e["w0"] = self._pack_conv(g(n + ".Conv_0.weight")); e["b0"] = self._dev(g(n + ".Conv_0.bias"))
+                e["w1"] = self._pack_conv(g(n + ".Conv_1.weight")); e["b1"] = self._dev(g(n + ".Conv_1.bias"))
+                if m["cin"] != m["cout"] or m["up"] or m["down"]:
+                    e["w2"] = self._pack_conv(g(n + ".Conv_2.weight")); e["b2"] = self._dev(g(n + ".Conv_2.bias"))
+                self.w[i] = e
+            elif k == "attn":
+                ws = [g(f"{n}.NIN_{j}.W") for j in range(4)]   # (in, out): conv weight is the transpose
+                bs = [g(f"{n}.NIN_{j}.b") for j in range(4)]
+                wqkv = torch.cat([w.t() for w in ws[:3]], 0)[:, :, None, None]
+                self.w[i] = dict(gamma=self._dev(g(n + ".GroupNorm_0.weight")),
+                                 beta=self._dev(g(n + ".GroupNorm_0.bias")),
+                                 wqkv=self._pack_conv(wqkv), bqkv=self._dev(torch.cat(bs[:3], 0)),
+                                 wo=self._pack_conv(ws[3].t()[:, :, None, None]), bo=self._dev(bs[3]))
+            elif k == "norm":
+                self.w[i] = dict(gamma=self._dev(g(n + ".Norm_0.weight")), beta=self._dev(g(n + ".Norm_0.bias")))
+        self.ss_total = off
+        self.temb_dim = dense_w[0].shape[1]
+        self.dense_w = self._pack_conv(torch.cat(dense_w, 0)[:, :, None, None])
+        self.dense_b = self._dev(torch.cat(dense_b, 0))
+
+    # ------------------------------------------------------------------------------------------
+    def _embedding(self, labels):
+        """get_timestep_embedding (models/better/layers.py:504-518) on the host, float32."""
+        dim = self.d.ngf
+        half = dim // 2
+        emb = math.log(10000) / (half - 1)
+        emb = torch.exp(torch.arange(half, dtype=torch.float32) * -emb)
+        emb = torch.tensor(labels, dtype=torch.float32)[:, None] * emb[None, :]
+        return torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
+
+    def prepare_labels(self, labels):
+        """Evaluate temb MLP + every AdaGN Dense_0 for the labels not in the table yet (one batched pass)."""
+        new = [float(v) for v in dict.fromkeys(float(x) for x in labels) if float(v) not in self._rows]
+        if not new:
+            return
+        R = len(new)
+        e = self._embedding(new).to(self.device).reshape(1, 1, R, self.d.ngf).contiguous()
+        w0, w1 = self.w[0], self.w[1]
+        t = L.conv2d_nhwc(e, w0["w"], w0["co"], 1, 1, bias=w0["b"])                       # Linear(ngf -> 4ngf)
+        t = L.conv2d_nhwc(t, w1["w"], w1["co"], 1, 1, bias=w1["b"], act_in=L.ACT_SILU)    # act -> Linear
+        rows = L.conv2d_nhwc(t, self.dense_w, self.ss_total, 1, 1, bias=self.dense_b, act_in=L.ACT_SILU)
+        base = self._table.shape[0]
+        self._table = torch.cat([self._table, rows.reshape(R, self.ss_total)], 0).contiguous()
+        self._row_tensors.clear()   # the table moved
+        for j, v in enumerate(new):
+            self._rows[v] = base + j
+
+    def _row_tensor(self, row_ids):
+        key = tuple(row_ids)
+        t = self._row_tensors.get(key)
+        if t is None:
+            t = torch.tensor(row_ids, dtype=torch.int32, device=self.device)
+            self._row_tensors[key] = t
+        return t
+
+    # ------------------------------------------------------------------------------------------
+    def _adagn(self, parts, hw, ch, seg, rows):
+        off, c = seg
+        assert c == ch
+        return L.gn_coeffs(parts, hw, num_groups(ch), 1e-5, mode=2, ss=self._table[:, off:off + 2 * c], row=rows)
+
+    def _res(self, i, m, x, skip, rows):
+        """ResnetBlockBigGANppGN.forward (models/better/layerspp.py:595-624)."""
+        e = self.w[i]
+        B, H, W, _ = x.t.shape
+        parts = [x.stats()] + ([skip.stats()] if skip is not None else [])
+        coef0 = self._adagn(parts, H * W, m["cin"], e["ss0"], rows)
+        if m["up"] or m["down"]:
+            if m["up"]:
+                k, up, down, pad = FIR_K * 4.0, 2, 1, (2, 1)     # upsample_2d: gain factor**2, pad (2, 1)
+            else:
+                k, up, down, pad = FIR_K, 1, 2, (1, 1)           # downsample_2d: pad (1, 1)
+            hf = L.upfirdn2d_nhwc(x.t, k, up, down, pad, coef=coef0, act=L.ACT_SILU)
+            xf = L.upfirdn2d_nhwc(x.t, k, up, down, pad)
+            h1 = _Act(L.conv2d_nhwc(hf, e["w0"], m["cout"], 3, 3, bias=e["b0"]))
+            xs_src, xs_skip = xf, None
+        else:
+            h1 = _Act(L.conv2d_nhwc(x.t, e["w0"], m["cout"], 3, 3, bias=e["b0"],
+                                    src1=None if skip is None else skip.t, coef=coef0, act_in=L.ACT_SILU))
+            xs_src, xs_skip = x.t, (None if skip is None else skip.t)
+        H1, W1 = h1.t.shape[1], h1.t.shape[2]
+        coef1 = self._adagn([h1.stats()], H1 * W1, m["cout"], e["ss1"], rows)
+        if "w2" in e:
+            xs = L.conv2d_nhwc(xs_src, e["w2"], m["cout"], 1, 1, bias=e["b2"], src1=xs_skip)
+        else:
+            xs = xs_src
+        out = L.conv2d_nhwc(h1.t, e["w1"], m["cout"], 3, 3, bias=e["b1"], coef=coef1, act_in=L.ACT_SILU, res=xs,
+                            out_scale=INV_SQRT2)
+        return _Act(out)
+
+    def _attn(self, i, m, x):
+        """AttnBlockpp.forward (models/better/layerspp.py:230-249)."""
+        e = self.w[i]
+        B, H, W, C = x.t.shape
+        hd = self.d.n_head_channels
+        heads = 1 if C < hd else C // hd
+        coef = L.gn_coeffs([x.stats()], H * W, num_groups(C), 1e-6, mode=1, gamma=e["gamma"], beta=e["beta"])
+        qkv = L.conv2d_nhwc(x.t, e["wqkv"], 3 * C, 1, 1, bias=e["bqkv"], coef=coef)
+        o = L.attention(qkv.view(B, H * W, 3 * C), C, heads)
+        out = L.conv2d_nhwc(o.view(B, H, W, C), e["wo"], C, 1, 1, bias=e["bo"], res=x.t, out_scale=INV_SQRT2)
+        return _Act(out)
+
+    @torch.no_grad()
+    def forward_rows(self, x, rows, cond=None):
+        """x: (B, C*num_frames, H, W) NCHW, rows: int32 (B,) device tensor of AdaGN-table rows."""
+        d = self.d
+        prog = self.program
+        B, _, H, W = x.shape
+        i = 2
+        m = prog[i]
+        xin = L.pack_nchw_to_nhwc(x, cond, self.w[i]["cin_pad"])
+        hs = [_Act(L.conv2d_nhwc(xin, self.w[i]["w"], m["cout"], 3, 3, bias=self.w[i]["b"]))]
+        i += 1
+        n_lvl = len(d.ch_mult)
+        for lvl in range(n_lvl):
+            for _ in range(d.num_res_blocks):
+                h = self._res(i, prog[i], hs[-1], None, rows); i += 1
+                if h.t.shape[2] in d.attn_resolutions:
+                    h = self._attn(i, prog[i], h); i += 1
+                hs.append(h)
+            if lvl != n_lvl - 1:
+                hs.append(self._res(i, prog[i], hs[-1], None, rows)); i += 1
+        h = hs[-1]
+        h = self._res(i, prog[i], h, None, rows); i += 1
+        h = self._attn(i, prog[i], h); i += 1
+        h = self._res(i, prog[i], h, None, rows); i += 1
+        for lvl in reversed(range(n_lvl)):
+            for _ in range(d.num_res_blocks + 1):
+                h = self._res(i, prog[i], h, hs.pop(), rows); i += 1
+            if h.t.shape[2] in d.attn_resolutions:
+                h = self._attn(i, prog[i], h); i += 1
+            if lvl != 0:
+                h = self._res(i, prog[i], h, None, rows); i += 1
+        assert not hs
+        e = self.w[i]
+        Bh, Hh, Wh, C = h.t.shape
+        coef = L.gn_coeffs([h.stats()], Hh * Wh, num_groups(C), 1e-5, mode=1, gamma=e["gamma"], beta=e["beta"])
+        i += 1
+        m = prog[i]
+        co = m["cout"]
+        out = torch.empty((B, H, W, _pad16(co)), device=x.device, dtype=torch.float32)
+        L.conv2d_nhwc(h.t, self.w[i]["w"], co, 3, 3, bias=self.w[i]["b"], coef=coef, act_in=L.ACT_SILU, out=out)
+        i += 1
+        assert i == len(prog)
+        return L.nhwc_to_nchw(out, co)
+
+    def forward_label(self, x, label, cond=None):
+        """All samples share one label (what every sampler does): no device->host sync."""
+        self.prepare_labels([label])
+        rows = self._row_tensor([self._rows[float(label)]] * x.shape[0])
+        return self.forward_rows(x, rows, cond)
+
+    def __call__(self, x, labels, cond=None, cond_mask=None):
+        """Reference call shape: ``scorenet(x, labels, cond=cond)`` (models/__init__.py:265,285)."""
+        vals = [float(v) for v in (labels.detach().cpu().tolist() if torch.is_tensor(labels) else labels)]
+        assert len(vals) == x.shape[0]
+        self.prepare_labels(vals)
+        rows = self._row_tensor([self._rows[v] for v in vals])
+        x = x.to(self.device, torch.float32)
+        cond = None if cond is None else cond.to(self.device, torch.float32)
+        return self.forward_rows(x, rows, cond)
+
+    forward = __call__
+
+    def eval(self):
+        return self

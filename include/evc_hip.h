@@ -1,0 +1,149 @@
+/* evc_hip.h -- C ABI of libevc_hip.so: the MI355X (gfx950) kernels of the decode hot path.
+ *
+ * Boundary rules: plain pointers and sizes, no torch types, the caller owns every
+ * buffer (no allocation inside), every call is stream-ordered on the `stream` argument
+ * (a hipStream_t passed as void*), returns 0 on success and a negative EVC_E* code otherwise,
+ * never throws.  All tensors are float32.  "NHWC" = [B][H][W][C] contiguous, C fastest.
+ *
+ * What each entry point replaces in the reference is cited next to it (paths relative to the
+ * reference repository root).
+ */
+#ifndef EVC_HIP_H
+#define EVC_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVC_OK 0
+#define EVC_EINVAL (-1)   /* bad shape / null pointer / misaligned channel count */
+#define EVC_EUNSUPPORTED (-2)
+#define EVC_ELAUNCH (-3)  /* hipGetLastError() != hipSuccess after the launch */
+
+#define EVC_ACT_NONE 0
+#define EVC_ACT_SILU 1
+#define EVC_ACT_RELU 2
+
+/* Library / device identification. evc_arch() returns the gfx target the code object was built
+ * for ("gfx950"). evc_device_ok() returns 1 when the current HIP device can run it. */
+const char* evc_version(void);
+const char* evc_arch(void);
+int evc_device_ok(void);
+
+/* ---- upfirdn2d: the reference's own native op ---------------------------------------------
+ * Replaces pybind `upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0,
+ * pad_y1)` (models/better/op/upfirdn2d.cpp:12-23, upfirdn2d_kernel.cu:209-243).  `input` is the
+ * reference's (major = N*C, in_h, in_w, minor = 1) view, i.e. NCHW planes; `out` must hold
+ * major*out_h*out_w floats with out_h = (in_h*up_y + pad_y0 + pad_y1 - kh)/down_y + 1 (same for w).
+ * The FIR kernel (kh*kw <= 64 taps) is a HOST pointer (it is 16 floats in this workload). */
+int evc_upfirdn2d_f32(const float* input, float* out, const float* kernel_host, int major, int in_h, int in_w,
+                      int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                      int pad_y0, int pad_y1, void* stream);
+
+/* Same maths on an NHWC tensor, with an optional per-(b,c) affine + activation applied to every
+ * input sample before filtering (zero padding stays zero).  Fuses get_act_norm + upsample_2d /
+ * downsample_2d of ResnetBlockBigGANppGN.forward (models/better/layerspp.py:596-611). */
+int evc_upfirdn2d_nhwc_f32(const float* x, float* out, const float* kernel_host, int B, int H, int W, int C,
+                           int kh, int kw, int up, int down, int pad0, int pad1, const float* coef_a,
+                           const float* coef_s, int act, void* stream);
+
+/* ---- layout -------------------------------------------------------------------------------
+ * Pack up to two NCHW tensors (x: C0 planes, cond: C1 planes) into one zero-padded NHWC tensor with
+ * Cpad channels: torch.cat([x, cond], 1) of NCSNpp.forward (models/better/ncsnpp_more.py:256-257). */
+int evc_pack_nchw_to_nhwc_f32(const float* x0, int C0, const float* x1, int C1, float* out, int Cpad, int B,
+                              int H, int W, void* stream);
+/* out[b][c][h][w] = in[b][h][w][c] for c < C; `ld` is the NHWC channel stride of `in`. */
+int evc_nhwc_to_nchw_f32(const float* in, int ld, float* out, int B, int C, int H, int W, void* stream);
+
+/* ---- GroupNorm ----------------------------------------------------------------------------
+ * Per-channel partial moments of an NHWC tensor: partial[b][s][c] = {sum, sum of squares} over the
+ * s-th of `nsplit` pixel ranges.  First half of nn.GroupNorm (models/better/layerspp.py:473-477). */
+int evc_chan_stats_f32(const float* x, float* partial, int B, int HW, int C, int nsplit, void* stream);
+
+/* Turn moments into per-(b,c) affine coefficients so that  norm(x) = x*coef_a + coef_s :
+ *   mode 0: plain group norm;  mode 1: * gamma + beta (AttnBlockpp.GroupNorm_0, final Norm_0);
+ *   mode 2: * (1 + scale) + shift, the AdaGN of get_act_norm.forward
+ *           (models/better/layerspp.py:518-549); scale = ss[row[b]*ss_ld + c], shift = ...[C + c].
+ * Channels come from up to two tensors (virtual concat, C = C0 + C1); groups may straddle them. */
+int evc_gn_coeffs_f32(const float* part0, int nsplit0, int C0, const float* part1, int nsplit1, int C1, int B,
+                      int HW, int groups, float eps, int mode, const float* gamma, const float* beta,
+                      const float* ss, int ss_ld, const int* row, float* coef_a, float* coef_s, void* stream);
+
+/* y = act(x*coef_a[b][c] + coef_s[b][c]) elementwise on NHWC (stand-alone form of the fused load). */
+int evc_affine_act_nhwc_f32(const float* x, float* y, const float* coef_a, const float* coef_s, int act, int B,
+                            int HW, int C, void* stream);
+
+/* ---- convolution as implicit GEMM on the f32 matrix cores ----------------------------------
+ * Stride-1 "same" convolution (odd KH x KW, zero padding) over the virtual concat [src0 | src1] of
+ * NHWC tensors.  Replaces nn.Conv2d 3x3 / 1x1 (models/better/layers.py:89-113), NIN
+ * (models/better/layers.py:535-544), nn.Linear (time-embedding MLP, Dense_0) and the ELIC conv
+ * stacks (Network.py:106-166).
+ *   in   = act_in(src * coef_a + coef_s)            (coef may be NULL; zero padding after act)
+ *   out  = act_out((conv(in, w) + bias + res) * out_scale)
+ * Weights are pre-packed by evc_conv_pack_weights_f32 into [KH*KW][Ci/16][CoPad][16].
+ * C0, C1 must be multiples of 16.  `ws` is a workspace of evc_conv_workspace_bytes() bytes
+ * (split-K partial sums; may be NULL when that returns 0). */
+typedef struct {
+    const float* src0; const float* src1; int C0; int C1;
+    const float* coef_a; const float* coef_s; int act_in;
+    const float* w_packed; const float* bias; const float* res; int ld_res;
+    float out_scale; int act_out;
+    float* out; int ld_out;
+    int B; int H; int W; int Co; int KH; int KW;
+    int splits;            /* 0 = choose automatically */
+} evc_conv_args;
+int evc_conv_co_pad(int Co);
+long long evc_conv_packed_floats(int Co, int Ci, int KH, int KW);
+/* w: [Co][Ci][KH][KW] (PyTorch Conv2d layout, device) -> packed (device). */
+int evc_conv_pack_weights_f32(const float* w, float* packed, int Co, int Ci, int KH, int KW, void* stream);
+int evc_conv_choose_splits(const evc_conv_args* a);
+long long evc_conv_workspace_bytes(const evc_conv_args* a);
+int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stream);
+
+/* ---- multi-head spatial self-attention ------------------------------------------------------
+ * out[b][n][h*D + d] = sum_m softmax_m(q[b][n][h].k[b][m][h] * scale) * v[b][m][h][d]
+ * q, k, v: [B][N][ld_*] token-major with head h at channel offset h*D; D in {32, 64, 192}.
+ * Replaces the two einsums + softmax of AttnBlockpp.forward (models/better/layerspp.py:241-246). */
+int evc_attention_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out, int B,
+                      int heads, int N, int D, float scale, void* stream);
+
+/* ---- sampler steps (elementwise, flat over n floats) ---------------------------------------- */
+/* DDPM ancestral step (models/__init__.py:289-330):
+ *   x0 = k1*(x - k2*e); clip; x = c1*x0 + c2*x (+ sigma*noise when noise != NULL). */
+int evc_ddpm_step_f32(float* x, const float* e, const float* noise, long long n, float k1, float k2, float c1,
+                      float c2, float sigma, int clip, void* stream);
+/* DDIM step (models/__init__.py:163-166): x = c1*clip(k1*(x - k2*e)) + c2*e. */
+int evc_ddim_step_f32(float* x, const float* e, long long n, float k1, float k2, float c1, float c2, int clip,
+                      void* stream);
+/* y = x + alpha*e  (final denoise call, models/__init__.py:333-335, with alpha = -sqrt(1-a)). */
+int evc_axpy_f32(const float* x, const float* e, float* y, long long n, float alpha, void* stream);
+/* PNDM transfer (models/pndm.py:19-33): y = clip(x + d*(cx*x - ce*e)). */
+int evc_pndm_transfer_f32(const float* x, const float* e, float* y, long long n, float d, float cx, float ce,
+                          int clip, void* stream);
+/* y = w0*e0 + w1*e1 + w2*e2 + w3*e3 (Runge-Kutta / Adams-Bashforth combination, pndm.py:15,47). */
+int evc_lincomb4_f32(const float* e0, const float* e1, const float* e2, const float* e3, float* y, long long n,
+                     float w0, float w1, float w2, float w3, void* stream);
+/* data_transform / inverse_data_transform (city_sender.py:232-244, function.py:73-82):
+ * y = x*mul + add, optionally clamped to [lo, hi]. */
+int evc_scale_clamp_f32(const float* x, float* y, long long n, float mul, float add, int clamp, float lo, float hi,
+                        void* stream);
+
+/* ---- ELIC helpers ---------------------------------------------------------------------------- */
+/* out = a * sigmoid(b) + x (AttentionBlock.forward, ELICUtilis/layers/layers.py:247-252). */
+int evc_gate_residual_f32(const float* a, const float* b, const float* x, float* out, long long n, void* stream);
+/* GaussianConditional.build_indexes on the checkerboard half of a slice (Network.py:488-496):
+ * for the anchor (parity 0) or non-anchor (parity 1) sites of scales [B][H][W][ld] at channel
+ * offset c0..c0+C, write idx[b][c][h][w/2] = #table entries logic of compressai build_indexes and the
+ * matching means[b][c][h][w/2]. */
+int evc_elic_gather_params_f32(const float* ms, int ld, int mean_off, int scale_off, int C, int B, int H, int W,
+                               int parity, const float* scale_table, int n_scales, int* idx, float* means,
+                               void* stream);
+/* y_hat[b][h][w][c0 + c] = symbols[b][c][h][w/2] + means (checkerboard sites of `parity`); other sites
+ * untouched (Network.py:498-499, 523-524). */
+int evc_elic_scatter_symbols_f32(const int* symbols, const float* means, float* y_hat, int ld, int c0, int C,
+                                 int B, int H, int W, int parity, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVC_HIP_H */

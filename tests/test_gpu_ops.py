@@ -1,0 +1,246 @@
+"""GPU parity tests, op level: every C-ABI kernel against a plain fp32 reference of the same op
+(torch on the same device and/or the CPU oracle), at small sizes.  Stated tolerances are relative to
+the reference's max magnitude; integer/index outputs must be exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import evc_amd  # noqa: F401
+    from evc_amd import lib
+    lib.hip_lib()   # raises if libevc_hip.so is missing or the device is not gfx950: no silent fallback
+    return lib
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def silu_affine(x, a, s):
+    return F.silu(x * a[:, :, None, None] + s[:, :, None, None])
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,K", [(2, 16, 16, 192, 192, 3), (1, 5, 7, 32, 48, 3), (2, 8, 8, 64, 15, 3),
+                                            (3, 8, 8, 96, 128, 1), (1, 9, 6, 32, 64, 5), (1, 1, 7, 192, 768, 1)])
+def test_conv_plain(L, B, H, W, Ci, Co, K):
+    x = rnd(1, B, Ci, H, W).cuda()
+    w = (rnd(2, Co, Ci, K, K) / np.sqrt(Ci * K * K)).cuda()
+    b = rnd(3, Co).cuda()
+    ref = F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=K // 2)
+    out = L.conv2d_nhwc(nhwc(x), L.conv_pack_weights(w), Co, K, K, bias=b)
+    assert out.shape == (B, H, W, Co)
+    assert rel(nchw(out), ref) < 1e-5
+
+
+@pytest.mark.parametrize("splits", [0, 1, 3, 7])
+def test_conv_fused_everything(L, splits):
+    """two-source concat + GroupNorm affine + SiLU on load + bias + residual + rescale (+ split-K)."""
+    B, H, W, C0, C1, Co = 2, 8, 8, 96, 64, 192
+    x0, x1 = rnd(4, B, C0, H, W).cuda(), rnd(5, B, C1, H, W).cuda()
+    a, s = (1 + 0.2 * rnd(6, B, C0 + C1)).cuda(), (0.3 * rnd(7, B, C0 + C1)).cuda()
+    w = (rnd(8, Co, C0 + C1, 3, 3) / np.sqrt(9 * (C0 + C1))).cuda()
+    b, res = rnd(9, Co).cuda(), rnd(10, B, Co, H, W).cuda()
+    xin = silu_affine(torch.cat([x0, x1], 1).cpu(), a.cpu(), s.cpu())
+    ref = (F.conv2d(xin, w.cpu(), b.cpu(), padding=1) + res.cpu()) * 0.70710678
+    out = L.conv2d_nhwc(nhwc(x0), L.conv_pack_weights(w), Co, 3, 3, bias=b, src1=nhwc(x1), coef=(a, s),
+                        act_in=L.ACT_SILU, res=nhwc(res), out_scale=0.70710678, splits=splits)
+    assert rel(nchw(out), ref) < 1e-5
+
+
+def test_conv_relu_in_out_and_wide_output_row(L):
+    B, H, W, Ci, Co = 1, 8, 8, 32, 16
+    x = rnd(11, B, Ci, H, W).cuda()
+    w = (rnd(12, Co, Ci, 3, 3) / np.sqrt(9 * Ci)).cuda()
+    ref = F.relu(F.conv2d(F.relu(x.cpu()), w.cpu(), None, padding=1))
+    out = torch.full((B, H, W, 24), 7.0, device="cuda")
+    L.conv2d_nhwc(nhwc(x), L.conv_pack_weights(w), Co, 3, 3, act_in=L.ACT_RELU, act_out=L.ACT_RELU, out=out)
+    assert rel(nchw(out[..., :Co]), ref) < 1e-5
+    assert bool((out[..., Co:] == 7.0).all())   # columns beyond Co are never written
+
+
+def test_conv_full_size_layer_vs_device_reference(L):
+    """3x3 192->192 at 128x128 (the dominant layer shape), B=2, against torch on the same device."""
+    B, H, W, C = 2, 128, 128, 192
+    x = rnd(13, B, C, H, W).cuda()
+    w = (rnd(14, C, C, 3, 3) / np.sqrt(9 * C)).cuda()
+    b = rnd(15, C).cuda()
+    ref = F.conv2d(x, w, b, padding=1)
+    out = L.conv2d_nhwc(nhwc(x), L.conv_pack_weights(w), C, 3, 3, bias=b)
+    assert rel(nchw(out), ref) < 2e-5
+
+
+def test_conv_rejects_bad_arguments(L):
+    x = torch.zeros(1, 4, 4, 24, device="cuda")   # 24 channels: not a multiple of 16
+    w = torch.zeros(64 * 2 * 16, device="cuda")
+    with pytest.raises(L.EvcKernelError):
+        L.conv2d_nhwc(x, w, 64, 3, 3)
+
+
+@pytest.mark.parametrize("B,H,W,C,G", [(2, 16, 16, 192, 32), (3, 8, 8, 1344, 32), (1, 32, 32, 32, 8), (2, 4, 4, 160, 32)])
+def test_groupnorm_via_moments_and_coeffs(L, B, H, W, C, G):
+    x = (rnd(20, B, C, H, W) * 1.7 + 0.4).cuda()
+    gamma, beta = (1 + 0.1 * rnd(21, C)).cuda(), (0.1 * rnd(22, C)).cuda()
+    xh = nhwc(x)
+    part = L.chan_stats(xh)
+    ca, cs = L.gn_coeffs([part], H * W, G, 1e-6, mode=1, gamma=gamma, beta=beta)
+    ref = F.group_norm(x.cpu(), G, gamma.cpu(), beta.cpu(), 1e-6)
+    assert rel(nchw(L.affine_act(xh, (ca, cs), L.ACT_NONE)), ref) < 1e-5
+    # AdaGN + SiLU with a two-row table and per-sample rows
+    ss = (0.2 * rnd(23, 2, 2 * C + 8)).cuda()
+    row = torch.tensor([1, 0, 1][:B], dtype=torch.int32, device="cuda")
+    ca, cs = L.gn_coeffs([part], H * W, G, 1e-5, mode=2, ss=ss[:, 8:], row=row)
+    sc = ss[row.long(), 8:8 + C].cpu()
+    sh = ss[row.long(), 8 + C:].cpu()
+    ref = F.silu(F.group_norm(x.cpu(), G, None, None, 1e-5) * (1 + sc[:, :, None, None]) + sh[:, :, None, None])
+    assert rel(nchw(L.affine_act(xh, (ca, cs), L.ACT_SILU)), ref) < 1e-5
+
+
+def test_groupnorm_groups_straddling_a_concat(L):
+    """cat[h (96 ch), skip (64 ch)] -> 160 channels in 32 groups of 5: groups cross the tensor boundary."""
+    B, H, W = 2, 8, 8
+    h, sk = rnd(24, B, 96, H, W).cuda(), (2 * rnd(25, B, 64, H, W) - 1).cuda()
+    ca, cs = L.gn_coeffs([L.chan_stats(nhwc(h)), L.chan_stats(nhwc(sk))], H * W, 32, 1e-5)
+    cat = torch.cat([h, sk], 1)
+    got = cat.cpu() * ca.cpu()[:, :, None, None] + cs.cpu()[:, :, None, None]
+    assert rel(got, F.group_norm(cat.cpu(), 32, None, None, 1e-5)) < 1e-5
+
+
+def test_upfirdn2d_dropin_against_reference_goldens(L):
+    g = golden("fir")
+    x = torch.from_numpy(g["x"]).cuda()
+    k = np.outer([1, 3, 3, 1], [1, 3, 3, 1]).astype(np.float32)
+    k /= k.sum()
+    up = L.upfirdn2d_nchw(x, k * 4, up=2, pad=(2, 1))
+    down = L.upfirdn2d_nchw(x, k, down=2, pad=(1, 1))
+    assert up.shape == g["up"].shape and down.shape == g["down"].shape
+    np.testing.assert_allclose(up.cpu().numpy(), g["up"], atol=2e-6)
+    np.testing.assert_allclose(down.cpu().numpy(), g["down"], atol=2e-6)
+    g2 = golden("upfirdn2d_generic")
+    x2, k2 = torch.from_numpy(g2["x"]).cuda(), g2["k"]
+    np.testing.assert_allclose(L.upfirdn2d_nchw(x2, k2, up=2, down=1, pad=(1, 0)).cpu().numpy(), g2["up2_pad10"], atol=3e-6)
+    np.testing.assert_allclose(L.upfirdn2d_nchw(x2, k2, up=1, down=3, pad=(2, 1)).cpu().numpy(), g2["down3_pad21"], atol=3e-6)
+    np.testing.assert_allclose(L.upfirdn2d_nchw(x2, k2, up=3, down=2, pad=(2, 2)).cpu().numpy(), g2["up3_down2_pad22"], atol=3e-6)
+
+
+def test_upfirdn2d_nhwc_with_fused_adagn_silu(L):
+    from oracle import upfirdn2d as O
+    B, C, H, W = 2, 32, 12, 10
+    x = rnd(30, B, C, H, W).cuda()
+    a, s = (1 + 0.2 * rnd(31, B, C)).cuda(), (0.3 * rnd(32, B, C)).cuda()
+    k = O.setup_kernel([1, 3, 3, 1])
+    act = silu_affine(x.cpu(), a.cpu(), s.cpu()).numpy()
+    got = L.upfirdn2d_nhwc(nhwc(x), k * 4, 2, 1, (2, 1), coef=(a, s), act=L.ACT_SILU)
+    np.testing.assert_allclose(nchw(got).cpu().numpy(), O.upsample_2d(act), atol=3e-6)
+    got = L.upfirdn2d_nhwc(nhwc(x), k, 1, 2, (1, 1), coef=(a, s), act=L.ACT_SILU)
+    np.testing.assert_allclose(nchw(got).cpu().numpy(), O.downsample_2d(act), atol=3e-6)
+    got = L.upfirdn2d_nhwc(nhwc(x), k, 1, 2, (1, 1))
+    np.testing.assert_allclose(nchw(got).cpu().numpy(), O.downsample_2d(x.cpu().numpy()), atol=3e-6)
+    # zero insertion used by the ELIC transposed convolutions: k = [[1]], up 2, pad (0, 0) -> 2H x 2W
+    got = L.upfirdn2d_nhwc(nhwc(x), np.ones((1, 1), np.float32), 2, 1, (0, 0))
+    z = torch.zeros(B, C, 2 * H, 2 * W)
+    z[:, :, ::2, ::2] = x.cpu()
+    assert torch.equal(nchw(got).cpu(), z)
+
+
+@pytest.mark.parametrize("B,heads,N,D", [(2, 2, 1024, 192), (1, 4, 64, 192), (2, 3, 256, 192), (2, 2, 96, 32), (1, 1, 64, 64)])
+def test_attention(L, B, heads, N, D):
+    C = heads * D
+    qkv = rnd(40, B, N, 3 * C).cuda()
+    out = L.attention(qkv, C, heads)
+    q, k, v = [t.reshape(B, N, heads, D).permute(0, 2, 1, 3) for t in qkv.cpu().split(C, dim=2)]
+    w = torch.softmax(torch.einsum("bhqd,bhkd->bhqk", q, k) * (D ** -0.5), dim=-1)
+    ref = torch.einsum("bhqk,bhkd->bhqd", w, v).permute(0, 2, 1, 3).reshape(B, N, C)
+    assert rel(out, ref) < 1e-5
+
+
+def test_attention_peaked_scores_exercise_the_rescale(L):
+    """large logits whose maximum moves to later key tiles force the online-softmax rescale branch."""
+    B, heads, N, D = 1, 1, 128, 32
+    C = D
+    q = rnd(41, B, N, C)
+    k = rnd(42, B, N, C) * torch.linspace(0.5, 6.0, N)[None, :, None]   # later keys dominate
+    v = rnd(43, B, N, C)
+    qkv = torch.cat([q, k, v], 2).cuda()
+    out = L.attention(qkv, C, heads)
+    w = torch.softmax(torch.einsum("bqd,bkd->bqk", q.double(), k.double()) * (D ** -0.5), dim=-1)
+    ref = torch.einsum("bqk,bkd->bqd", w, v.double()).float()
+    assert rel(out, ref) < 2e-5
+
+
+def test_layout_pack_and_unpack(L):
+    B, H, W = 2, 6, 10
+    x, c = rnd(50, B, 15, H, W).cuda(), rnd(51, B, 6, H, W).cuda()
+    p = L.pack_nchw_to_nhwc(x, c, 32)
+    ref = torch.zeros(B, H, W, 32)
+    ref[..., :15] = nhwc(x).cpu()
+    ref[..., 15:21] = nhwc(c).cpu()
+    assert torch.equal(p.cpu(), ref)
+    assert torch.equal(L.nhwc_to_nchw(p, 15).cpu(), x.cpu())
+    assert torch.equal(L.pack_nchw_to_nhwc(x, None, 16).cpu()[..., :15], nhwc(x).cpu())
+
+
+def test_sampler_step_kernels(L):
+    n = (2, 15, 8, 8)
+    x, e, z = rnd(60, *n).cuda(), rnd(61, *n).cuda(), rnd(62, *n).cuda()
+    k1, k2, c1, c2, sg = 1.3, 0.7, 0.4, 0.55, 0.2
+    x0 = (k1 * (x - k2 * e)).clip(-1, 1)
+    ref = c1 * x0 + c2 * x + sg * z
+    y = x.clone(); L.ddpm_step(y, e, z, k1, k2, c1, c2, sg, True)
+    assert rel(y, ref) < 1e-6
+    y = x.clone(); L.ddpm_step(y, e, None, k1, k2, c1, c2, sg, True)
+    assert rel(y, c1 * x0 + c2 * x) < 1e-6
+    y = x.clone(); L.ddim_step(y, e, k1, k2, c1, c2, False)
+    assert rel(y, c1 * (k1 * (x - k2 * e)) + c2 * e) < 1e-6
+    assert rel(L.axpy(x, e, -0.3), x - 0.3 * e) < 1e-6
+    assert rel(L.pndm_transfer(x, e, 0.1, 0.8, 1.1, True), (x + 0.1 * (0.8 * x - 1.1 * e)).clip(-1, 1)) < 1e-6
+    assert rel(L.lincomb4([x, e, z, x], [55 / 24, -59 / 24, 37 / 24, -9 / 24]),
+               (55 * x - 59 * e + 37 * z - 9 * x) / 24) < 1e-6
+    assert rel(L.lincomb4([x, e], [0.5, 2.0]), 0.5 * x + 2 * e) < 1e-6
+    assert rel(L.scale_clamp(x, 0.5, 0.5, (0.0, 1.0)), ((x + 1) / 2).clamp(0, 1)) < 1e-6
+    assert rel(L.gate_residual(x, e, z), x * torch.sigmoid(e) + z) < 1e-6
+
+
+def test_elic_checkerboard_gather_scatter(L):
+    B, H, W, C, ld = 2, 8, 8, 16, 40
+    ms = torch.zeros(B, H, W, ld)
+    means = rnd(70, B, H, W, C)
+    scales = rnd(71, B, H, W, C).abs() * 3
+    ms[..., 4:4 + C], ms[..., 24:24 + C] = means, scales
+    table = torch.exp(torch.linspace(np.log(0.11), np.log(256), 64))
+    for parity in (0, 1):
+        idx, mu = L.elic_gather_params(ms.cuda(), 4, 24, C, parity, table.cuda())
+        m_nchw, s_nchw = means.permute(0, 3, 1, 2), scales.permute(0, 3, 1, 2)
+        m_enc, s_enc = torch.zeros(B, C, H, W // 2), torch.zeros(B, C, H, W // 2)
+        o0, o1 = (0, 1) if parity == 0 else (1, 0)
+        m_enc[:, :, 0::2], m_enc[:, :, 1::2] = m_nchw[:, :, 0::2, o0::2], m_nchw[:, :, 1::2, o1::2]
+        s_enc[:, :, 0::2], s_enc[:, :, 1::2] = s_nchw[:, :, 0::2, o0::2], s_nchw[:, :, 1::2, o1::2]
+        ref_idx = torch.full(s_enc.shape, 63, dtype=torch.int32)
+        sc = s_enc.clamp(min=0.11)
+        for s in table[:-1]:
+            ref_idx -= (sc <= s).int()
+        assert torch.equal(idx.cpu(), ref_idx)
+        assert torch.equal(mu.cpu(), m_enc)
+        sym = torch.randint(-5, 6, (B, C, H, W // 2), dtype=torch.int32)
+        y = torch.zeros(B, H, W, 48, device="cuda")
+        L.elic_scatter_symbols(sym.cuda(), mu, y, 32, parity)
+        full = torch.zeros(B, C, H, W)
+        q = sym.float() + m_enc
+        full[:, :, 0::2, o0::2], full[:, :, 1::2, o1::2] = q[:, :, 0::2], q[:, :, 1::2]
+        assert torch.equal(y.cpu()[..., 32:48].permute(0, 3, 1, 2), full)
+        assert float(y.cpu()[..., :32].abs().max()) == 0.0

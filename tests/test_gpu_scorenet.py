@@ -1,0 +1,111 @@
+"""GPU parity tests, network and sampler level: the HIP score network and sampling loops against the
+golden vectors produced by the reference itself (tests/golden/make_goldens.py) and against the CPU oracle
+on the same seeded weights and inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+def make_config(ngf, head, image_size):
+    import evc_amd  # noqa: F401
+    from evc_amd.config import default_config
+    return default_config(ngf, head, image_size)
+
+
+def build(ngf, head, image_size, seed):
+    import evc_amd  # noqa: F401
+    from evc_amd.scorenet import ScoreNet
+    from oracle.scorenet import Dims, seeded_params
+    d = Dims(ngf=ngf, n_head_channels=head, image_size=image_size)
+    p = seeded_params(d, seed)
+    return ScoreNet(make_config(ngf, head, image_size), p), d, p
+
+
+def rel(a, b):
+    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else a
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_forward_ngf64_against_reference_golden():
+    net, d, p = build(64, 64, 32, 21)
+    x, cond = rnd(22, 2, 15, 32, 32).cuda(), rnd(23, 2, 6, 32, 32).cuda()
+    out = net(x, torch.tensor([430, 430]), cond=cond)
+    assert out.shape == (2, 15, 32, 32)
+    assert rel(out, golden("blocks_ngf64")["out"]) < 1e-4   # fp32, tolerance of SURVEY.md 8c
+
+
+def test_forward_ngf32_three_labels_incl_fractional_and_mixed_batch():
+    g = golden("forward_ngf32")
+    net, d, p = build(32, 32, 32, 31)
+    x, cond = rnd(32, 2, 15, 32, 32).cuda(), rnd(33, 2, 6, 32, 32).cuda()
+    for key, lab in (("out_t0", [0, 0]), ("out_t990", [990, 990]), ("out_tm05", [-0.5, -0.5])):
+        assert rel(net(x, torch.tensor(lab), cond=cond), g[key]) < 1e-4, key
+    mixed = net(x, torch.tensor([0, 990]), cond=cond)     # per-sample labels through the row table
+    assert rel(mixed[0], g["out_t0"][0]) < 1e-4 and rel(mixed[1], g["out_t990"][1]) < 1e-4
+
+
+def test_forward_full_size_against_reference_golden():
+    g = golden("forward_full")
+    net, d, p = build(192, 192, 128, 1234)
+    x, cond = rnd(51, 1, 15, 128, 128).cuda(), rnd(52, 1, 6, 128, 128).cuda()
+    o = net(x, torch.tensor([500]), cond=cond).cpu()
+    assert rel(o.reshape(-1)[::60].numpy(), g["samples"]) < 2e-4
+    assert rel(o[0, :, 0, :].numpy(), g["first_row"]) < 2e-4
+    # batch invariance at full size: B=3 with identical samples gives identical outputs per sample
+    o3 = net(x.repeat(3, 1, 1, 1), torch.tensor([500] * 3), cond=cond.repeat(3, 1, 1, 1)).cpu()
+    assert rel(o3[2], o[0].numpy()) < 1e-5
+
+
+def test_sampler_trajectories_against_reference_goldens():
+    import evc_amd  # noqa: F401
+    from evc_amd import sampler
+    g = golden("samplers_ngf32")
+    net, d, p = build(32, 32, 32, 41)
+    x_T, cond = rnd(42, 2, 15, 32, 32).cuda(), rnd(43, 2, 6, 32, 32).cuda()
+    noises = [rnd(100 + i, 2, 15, 32, 32) for i in range(5)]
+    out = sampler.ddpm_sampler(x_T, net, cond=cond, subsample_steps=5, denoise=True, clip_before=True,
+                               final_only=True, noise_fn=lambda i, x: noises[i])
+    assert out.shape == g["ddpm"].shape and rel(out, g["ddpm"]) < 5e-4
+    out = sampler.ddim_sampler(x_T, net, cond=cond, subsample_steps=5, denoise=True, clip_before=True, final_only=True)
+    assert rel(out, g["ddim"]) < 5e-4
+    out = sampler.FPNDM_sampler(x_T, net, cond=cond, subsample_steps=10, final_only=True, clip_before=True)
+    assert rel(out, g["fpndm"]) < 5e-4
+
+
+def test_sampler_label_sequences_match_reference():
+    import evc_amd  # noqa: F401
+    from evc_amd import sampler
+    g = golden("label_sequences")
+
+    class Fake:
+        def __init__(self):
+            from oracle.schedule import base_schedule
+            self.betas, self.alphas, self.alphas_prev = base_schedule()
+            self.log = []
+
+        def __call__(self, x, labels, cond=None):
+            self.log.append(float(labels[0]))
+            return 0.1 * x
+    x = rnd(42, 2, 15, 32, 32).cuda()
+    for key, fn, kw in (("labels_ddpm", sampler.ddpm_sampler, dict(subsample_steps=2, denoise=True)),
+                        ("labels_ddim", sampler.ddim_sampler, dict(subsample_steps=4, denoise=True)),
+                        ("labels_fpndm", sampler.FPNDM_sampler, dict(subsample_steps=4)),
+                        ("labels_fpndm10", sampler.FPNDM_sampler, dict(subsample_steps=10)),
+                        ("labels_ddpm100", sampler.ddpm_sampler, dict(subsample_steps=100, denoise=True))):
+        f = Fake()
+        fn(x, f, final_only=True, **kw)
+        np.testing.assert_array_equal(np.asarray(f.log), g[key])
+
+
+def test_hip_net_against_cpu_oracle_same_weights():
+    """The oracle (pinned by the goldens) and the HIP path on fresh seeded inputs the goldens do not hold."""
+    from oracle import scorenet as O
+    net, d, p = build(32, 32, 32, 77)
+    x, cond = rnd(78, 3, 15, 32, 32), rnd(79, 3, 6, 32, 32)
+    ref = O.forward(p, d, x, torch.tensor([120, 120, 120]), cond=cond)
+    out = net(x.cuda(), torch.tensor([120, 120, 120]), cond=cond.cuda())
+    assert rel(out, ref.numpy()) < 1e-4
