@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Benchmark of the decode hot path on MI355X: decoded frames/s for 30-frame 128x128 clips at q3.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the receiver over one batch of clips per GPU (BASELINE.json configs[1]: 9 clips =
+city_bonn[0..8], q3): per clip 2 ELIC key frames are entropy-decoded + synthesised and 28 frames are generated
+by 6 diffusion chunks (DDPM, 1000-step schedule subsampled to 100, + 1 denoise call = 101 score-network
+forwards per chunk, fp32).  Weak scaling: every GPU decodes its own 9 clips; no data-path collective
+(clips are independent); weights are broadcast once from rank 0 over RCCL before timing.
+Synthetic data, seeded random weights of the reference architecture (no checkpoints / dataset offline).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (conv_igemm_kernel<3>, f32 MFMA implicit-GEMM convolution): algorithmic
+                  FLOPs per launch / average launch duration measured live with HIP events on the launch stream
+  cpu_baseline -- the CPU oracle (a port, kind "port") timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FWD_FLOP_PER_SAMPLE = 345_201_475_584      # one score-network forward, one sample
+ELIC_DECODE_FLOP = 10.865e9                # one 128x128 key-frame decode
+F32_MFMA_PEAK_TFLOPS = 157.3               # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix == vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clips", type=int, default=9, help="clips per GPU per step (configs[1]: start 0 end 8)")
+    ap.add_argument("--subsample", type=int, default=100)
+    ap.add_argument("--sampler", default="DDPM", choices=["DDPM", "DDIM", "FPNDM"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def roofline_leg(net, clips, device):
+    """One profiled forward at the benchmark batch size: HIP events around every conv launch."""
+    from evc_amd import lib as L
+    x = torch.randn(clips, 15, 128, 128, device=device)
+    c = torch.randn(clips, 6, 128, 128, device=device)
+    net.forward_label(x, 500, c)            # warm
+    torch.cuda.synchronize()
+    prof = []
+    L.CONV_PROFILE = prof
+    for _ in range(3):
+        net.forward_label(x, 500, c)
+    L.CONV_PROFILE = None
+    torch.cuda.synchronize()
+    per = {}
+    for r in prof:
+        v = per.setdefault(r["variant"], dict(n=0, ms=0.0, flops=0.0))
+        v["n"] += 1
+        v["ms"] += r["e0"].elapsed_time(r["e1"])
+        v["flops"] += r["flops"]
+    dom = max(per, key=lambda k: per[k]["ms"])
+    d = per[dom]
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    total_conv_ms = sum(v["ms"] for v in per.values()) / 3
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": f"conv_igemm_kernel<{dom}>", "launches_per_forward": d["n"] // 3,
+            "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 2),
+            "algorithmic_gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 3),
+            "conv_ms_per_forward": round(total_conv_ms, 3), "batch": clips}
+
+
+def cpu_baseline_leg(sd, cfg, seconds):
+    """The CPU oracle (oracle/scorenet.py, a port of the reference's PyTorch-CPU path) on this box's host cores.
+    Sample: whole score-network forwards at B=1; frames/s = 5 generated frames / (101 forwards per chunk)."""
+    from oracle import scorenet as ON
+    d = ON.Dims()
+    p = {k: v.cpu() for k, v in sd.items() if k.startswith("unet.all_modules.")}
+    x, c = torch.randn(1, 15, 128, 128), torch.randn(1, 6, 128, 128)
+    lab = torch.tensor([500])
+    ON.forward(p, d, x, lab, cond=c)     # warm
+    n, t0 = 0, time.time()
+    while time.time() - t0 < seconds and n < 40:
+        ON.forward(p, d, x, lab, cond=c)
+        n += 1
+    t = (time.time() - t0) / n
+    cores = torch.get_num_threads()
+    return {"value": round(5.0 / (101 * t), 5), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fp32 score-network forwards (B=1, 345.2 GFLOP each, {t:.3f} s/forward, "
+                      f"torch CPU {cores} threads); generated frames/s = 5/(101*t); ELIC key frames excluded"}
+
+
+def main():
+    a = parse()
+    import evc_amd  # noqa: F401
+    from evc_amd import dist as D, lib as L, sampler as S, synthetic
+    from evc_amd.config import default_config
+    from evc_amd.decoder import ClipDecoder, all_generated_mask
+    from evc_amd.elic import ElicModel
+    from evc_amd.scorenet import ScoreNet
+
+    rank, world, device = D.init()
+    if world != a.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    L.hip_lib()
+    torch.cuda.set_device(device)
+    cfg = default_config(192, 192, 128, subsample=a.subsample)
+
+    # weights: rank 0 owns the (synthetic, reference-layout) checkpoints; ONE broadcast per model over RCCL
+    sd_d = synthetic.diffusion_state_dict(cfg, 1234) if rank == 0 else None
+    sd_e = synthetic.elic_state_dict(3) if rank == 0 else None     # quality index 3 (q3)
+    sd_d = D.broadcast_state_dict(sd_d, src=0, device=device, world=world)
+    sd_e = D.broadcast_state_dict(sd_e, src=0, device=device, world=world)
+    net = ScoreNet(cfg, sd_d, device=device)
+    elic = ElicModel(sd_e, device=device)
+    dec = ClipDecoder(net, elic, cfg, S.get_sampler(a.sampler))
+
+    # inputs: this rank's clips; key frames 0,1 are ELIC-encoded once (sender side, untimed)
+    clips = torch.from_numpy(synthetic.make_clips(a.clips, seed=100 + rank).astype(np.float32) / 255.0)
+    key_strings, shape = [], None
+    for f in range(2):
+        enc = elic.compress(clips[:, f].to(device))
+        key_strings.append(enc["strings"])
+        shape = enc["shape"]
+    d = all_generated_mask()
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+
+    def step():
+        return dec.decode(d, key_strings, shape, generator=gen)
+
+    for _ in range(a.warmup):
+        step()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        frames = step()
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
+    assert frames.shape == (a.clips, 30, 3, 128, 128) and bool(torch.isfinite(frames).all())
+
+    n_frames = world * a.clips * 30 * a.steps
+    value = n_frames / elapsed
+    fwd_per_chunk = {"DDPM": a.subsample + 1, "DDIM": a.subsample + 1, "FPNDM": 12 + (a.subsample - 3)}[a.sampler]
+    flop_per_step_gpu = a.clips * (6 * fwd_per_chunk * FWD_FLOP_PER_SAMPLE + 2 * ELIC_DECODE_FLOP)
+    out = {"metric": "decoded frames/sec (128x128x30) at q3", "value": round(value, 4), "unit": "frames/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"configs[1]: {a.clips} clips/GPU x 30 frames 128x128, q3, 2 ELIC key frames + "
+                                  f"6 chunks x {fwd_per_chunk} forwards ({a.sampler}-{a.subsample}), B={a.clips} per launch",
+                      "parallelism": f"clip-sharded dp{world}, no data-path collective",
+                      "weights": "seeded random, reference architecture (262.1M + ELIC)"},
+           "whole_path_tflops_per_gpu": round(flop_per_step_gpu * a.steps / elapsed / 1e12, 2)}
+    if rank == 0:
+        out["roofline"] = roofline_leg(net, a.clips, device)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_leg(sd_d, cfg, a.cpu_baseline_seconds)
+        else:
+            out["cpu_baseline"] = None
+    D.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -27,7 +27,7 @@ constexpr int KC = 16;       // channels per K step
 constexpr int LDS_LD = 20;   // padded LDS row (floats)
 
 struct ConvK {
-    const float* src0; const float* src1; int C0; int C1;
+    const float* src0; const float* src1; int C0; int C1; int ld0; int ld1;
     const float* coef_a; const float* coef_s; int act_in;
     const float* w; const float* bias; const float* res; int ld_res;
     float out_scale; int act_out;
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         const int dx = tap - (tap / p.KW) * p.KW - padW;
         const int c = chunk * KC;
         const float* src; int cs_off, Csrc;
-        if (c < p.C0) { src = p.src0; cs_off = c; Csrc = p.C0; }
-        else { src = p.src1; cs_off = c - p.C0; Csrc = p.C1; }
+        if (c < p.C0) { src = p.src0; cs_off = c; Csrc = p.ld0; }
+        else { src = p.src1; cs_off = c - p.C0; Csrc = p.ld1; }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int yy = ry[i] + dy, xx = rx[i] + dx;
@@ -270,6 +270,8 @@ static int conv_validate(const evc_conv_args* a) {
     if (!a || !a->src0 || !a->w_packed || !a->out) return EVC_EINVAL;
     if (a->C0 <= 0 || a->C0 % KC != 0 || a->C1 < 0 || a->C1 % KC != 0) return EVC_EINVAL;
     if (a->C1 > 0 && !a->src1) return EVC_EINVAL;
+    if ((a->ld0 != 0 && (a->ld0 < a->C0 || (a->ld0 & 3))) || (a->ld1 != 0 && (a->ld1 < a->C1 || (a->ld1 & 3))))
+        return EVC_EINVAL;
     if ((a->coef_a == nullptr) != (a->coef_s == nullptr)) return EVC_EINVAL;
     if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Co <= 0) return EVC_EINVAL;
     if (a->KH <= 0 || a->KW <= 0 || !(a->KH & 1) || !(a->KW & 1)) return EVC_EINVAL;
@@ -311,6 +313,7 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     if (rc != EVC_OK) return rc;
     ConvK k;
     k.src0 = a->src0; k.src1 = a->src1; k.C0 = a->C0; k.C1 = a->C1;
+    k.ld0 = a->ld0 > 0 ? a->ld0 : a->C0; k.ld1 = a->ld1 > 0 ? a->ld1 : a->C1;
     k.coef_a = a->coef_a; k.coef_s = a->coef_s; k.act_in = a->act_in;
     k.w = a->w_packed; k.bias = a->bias; k.res = a->res; k.ld_res = a->ld_res;
     k.out_scale = a->out_scale; k.act_out = a->act_out; k.out = a->out; k.ld_out = a->ld_out;

@@ -146,6 +146,20 @@ __global__ void elic_scatter_symbols_kernel(const int* __restrict__ sym, const f
     }
 }
 
+__global__ void elic_quantize_kernel(const float* __restrict__ y, int ld, int c0, const float* __restrict__ means,
+                                     int C, int H, int W, int parity, int* __restrict__ sym, size_t total) {
+    const int Wh = W >> 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % Wh);
+        size_t r = i / Wh;
+        const int h = (int)(r % H); r /= H;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        const int w = cb_col(h, j, parity);
+        sym[i] = (int)rintf(y[((size_t)(b * H + h) * W + w) * ld + c0 + c] - means[i]);   // round half to even
+    }
+}
+
 }  // namespace
 
 extern "C" int evc_pack_nchw_to_nhwc_f32(const float* x0, int C0, const float* x1, int C1, float* out, int Cpad,
@@ -240,5 +254,16 @@ extern "C" int evc_elic_scatter_symbols_f32(const int* symbols, const float* mea
     const size_t total = (size_t)B * C * H * (W >> 1);
     hipLaunchKernelGGL(elic_scatter_symbols_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, symbols,
                        means, y_hat, ld, c0, C, H, W, parity, total);
+    return EVC_LAUNCH_OK();
+}
+
+extern "C" int evc_elic_quantize_f32(const float* y, int ld, int c0, const float* means, int C, int B, int H, int W,
+                                     int parity, int* symbols, void* stream) {
+    if (!y || !means || !symbols || C <= 0 || c0 < 0 || c0 + C > ld || B <= 0 || H <= 0 || W <= 0 || (W & 1) ||
+        parity < 0 || parity > 1)
+        return EVC_EINVAL;
+    const size_t total = (size_t)B * C * H * (W >> 1);
+    hipLaunchKernelGGL(elic_quantize_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, y, ld, c0,
+                       means, C, H, W, parity, symbols, total);
     return EVC_LAUNCH_OK();
 }

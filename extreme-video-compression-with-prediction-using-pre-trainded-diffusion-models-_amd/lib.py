@@ -29,6 +29,7 @@ class EvcKernelError(RuntimeError):
 class ConvArgs(ctypes.Structure):
     """Mirror of ``evc_conv_args`` (include/evc_hip.h)."""
     _fields_ = [("src0", c_void_p), ("src1", c_void_p), ("C0", c_int), ("C1", c_int),
+                ("ld0", c_int), ("ld1", c_int),
                 ("coef_a", c_void_p), ("coef_s", c_void_p), ("act_in", c_int),
                 ("w_packed", c_void_p), ("bias", c_void_p), ("res", c_void_p), ("ld_res", c_int),
                 ("out_scale", c_float), ("act_out", c_int),
@@ -74,6 +75,7 @@ HIP_SYMBOLS = {
     "evc_elic_gather_params_f32": (c_int, [c_void_p] + [c_int] * 8 + [c_void_p, c_int, c_void_p, c_void_p,
                                                                        c_void_p]),
     "evc_elic_scatter_symbols_f32": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "evc_elic_quantize_f32": (c_int, [c_void_p, c_int, c_int, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p]),
 }
 
 RANS_SYMBOLS = {
@@ -267,6 +269,16 @@ def conv_pack_weights(w):
 
 _ws_cache = {}
 
+# Optional launch profiler (bench.py roofline leg): when a list is installed here every conv launch is
+# bracketed by HIP events recorded on the stream the kernel runs on.
+CONV_PROFILE = None
+
+
+def conv_variant(Co):
+    """Which conv_igemm_kernel<TN> instantiation serves an output width (mirrors pick_tn in conv_igemm.hip)."""
+    cp = (Co + 63) // 64 * 64
+    return 3 if cp % 192 == 0 else (2 if cp % 128 == 0 else 1)
+
 
 def _workspace(nbytes, device):
     """Grow-only split-K workspace per device (stream-ordered reuse on the current stream)."""
@@ -278,24 +290,57 @@ def _workspace(nbytes, device):
     return cur
 
 
+class Cols:
+    """A channel slice [c0, c0 + C) of a contiguous NHWC tensor, usable as a conv source or destination."""
+    __slots__ = ("t", "c0", "C")
+
+    def __init__(self, t, c0, C):
+        assert t.is_contiguous() and 0 <= c0 and c0 + C <= t.shape[-1] and c0 % 4 == 0
+        self.t, self.c0, self.C = t, c0, C
+
+
+def _src(s):
+    """-> (pointer, channels, row stride, shape[:3])"""
+    if s is None:
+        return None, 0, 0, None
+    if isinstance(s, Cols):
+        return c_void_p(s.t.data_ptr() + 4 * s.c0), s.C, s.t.shape[-1], s.t.shape[:3]
+    return ptr(s), s.shape[-1], s.shape[-1], s.shape[:3]
+
+
 def conv2d_nhwc(src0, w_packed, Co, KH, KW, bias=None, src1=None, coef=None, act_in=ACT_NONE, res=None,
                 out_scale=1.0, act_out=ACT_NONE, out=None, splits=0):
-    """out = act_out((conv(act_in(cat[src0,src1]*a+s), w) + bias + res) * out_scale); tensors are NHWC."""
+    """out = act_out((conv(act_in(cat[src0,src1]*a+s), w) + bias + res) * out_scale); tensors are NHWC.
+    ``src0`` / ``src1`` / ``out`` may be ``Cols`` channel slices of wider tensors."""
     L = hip_lib()
-    B, H, W, C0 = src0.shape
-    C1 = 0 if src1 is None else src1.shape[3]
+    p0, C0, ld0, shp = _src(src0)
+    p1, C1, ld1, shp1 = _src(src1)
+    assert shp1 is None or tuple(shp1) == tuple(shp)
+    B, H, W = shp
+    dev = (src0.t if isinstance(src0, Cols) else src0).device
     if out is None:
-        out = torch.empty((B, H, W, Co), device=src0.device, dtype=torch.float32)
+        out = torch.empty((B, H, W, Co), device=dev, dtype=torch.float32)
+    po, Cout, ldo, shpo = _src(out)
+    assert tuple(shpo) == (B, H, W) and Cout >= Co
     ca, cs = coef if coef is not None else (None, None)
-    a = ConvArgs(ptr(src0), ptr(src1), C0, C1, ptr(ca), ptr(cs), act_in, ptr(w_packed), ptr(bias), ptr(res),
-                 0 if res is None else res.shape[-1], float(out_scale), act_out, ptr(out), out.shape[-1],
+    a = ConvArgs(p0, p1, C0, C1, ld0, ld1, ptr(ca), ptr(cs), act_in, ptr(w_packed), ptr(bias), ptr(res),
+                 0 if res is None else res.shape[-1], float(out_scale), act_out, po, ldo,
                  B, H, W, Co, KH, KW, splits)
     nbytes = L.evc_conv_workspace_bytes(ctypes.byref(a))
     if nbytes < 0:
         raise EvcKernelError(f"evc_conv_workspace_bytes rejected the arguments ({nbytes})")
-    ws = _workspace(nbytes, src0.device) if nbytes > 0 else None
+    ws = _workspace(nbytes, dev) if nbytes > 0 else None
+    if CONV_PROFILE is not None:
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
     _check(L.evc_conv2d_nhwc_f32(ctypes.byref(a), ptr(ws), stream_ptr()), "evc_conv2d_nhwc_f32")
-    return out
+    if CONV_PROFILE is not None:
+        e1.record(st)
+        CONV_PROFILE.append(dict(variant=conv_variant(Co), split=nbytes > 0, e0=e0, e1=e1,
+                                 flops=2.0 * B * H * W * Co * KH * KW * (C0 + C1),
+                                 shape=(B, H, W, C0 + C1, Co, KH)))
+    return out.t if isinstance(out, Cols) else out
 
 
 def attention(qkv, C, heads, out=None):
@@ -379,6 +424,15 @@ def elic_scatter_symbols(symbols, means, y_hat, c0, parity):
     _check(hip_lib().evc_elic_scatter_symbols_f32(fptr(symbols, torch.int32), fptr(means), fptr(y_hat),
                                                   y_hat.shape[-1], c0, C, B, H, 2 * Wh, parity, stream_ptr()),
            "evc_elic_scatter_symbols_f32")
+
+
+def elic_quantize(y, c0, means, parity):
+    """y: (B, H, W, ld); means: (B, C, H, W/2) -> int32 symbols (B, C, H, W/2)."""
+    B, C, H, Wh = means.shape
+    sym = torch.empty((B, C, H, Wh), device=y.device, dtype=torch.int32)
+    _check(hip_lib().evc_elic_quantize_f32(fptr(y), y.shape[-1], c0, fptr(means), C, B, H, 2 * Wh, parity,
+                                           fptr(sym, torch.int32), stream_ptr()), "evc_elic_quantize_f32")
+    return sym
 
 
 # ---- host rANS -------------------------------------------------------------------------------

@@ -85,6 +85,8 @@ int evc_affine_act_nhwc_f32(const float* x, float* y, const float* coef_a, const
  * (split-K partial sums; may be NULL when that returns 0). */
 typedef struct {
     const float* src0; const float* src1; int C0; int C1;
+    int ld0; int ld1;      /* row strides (floats) of src0 / src1; 0 = C0 / C1 (dense). Lets a source be a
+                              channel slice of a wider NHWC tensor. Must be multiples of 4. */
     const float* coef_a; const float* coef_s; int act_in;
     const float* w_packed; const float* bias; const float* res; int ld_res;
     float out_scale; int act_out;
@@ -142,6 +144,10 @@ int evc_elic_gather_params_f32(const float* ms, int ld, int mean_off, int scale_
  * untouched (Network.py:498-499, 523-524). */
 int evc_elic_scatter_symbols_f32(const int* symbols, const float* means, float* y_hat, int ld, int c0, int C,
                                  int B, int H, int W, int parity, void* stream);
+/* Encoder side (Network.py:399, 423 via compressai quantize "symbols"): symbols[b][c][h][w/2] =
+ * round_half_even(y[b][h][w][c0 + c] - means[b][c][h][w/2]) at the checkerboard sites of `parity`. */
+int evc_elic_quantize_f32(const float* y, int ld, int c0, const float* means, int C, int B, int H, int W,
+                          int parity, int* symbols, void* stream);
 
 #ifdef __cplusplus
 }

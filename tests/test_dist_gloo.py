@@ -1,0 +1,67 @@
+"""world_size-2 CPU (gloo) tests of the multi-GPU plumbing: shard plan and the one-shot weight broadcast."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import evc_amd  # noqa: F401
+    from evc_amd import dist as D
+    r, w, dev = D.init(backend="gloo")
+    g = torch.Generator().manual_seed(5)
+    sd = None
+    if r == 0:
+        sd = {"a.weight": torch.randn(7, 3, generator=g), "b.bias": torch.randn(5, generator=g),
+              "tab._cdf": torch.arange(12, dtype=torch.int32).reshape(3, 4), "c.weight": torch.randn(2, 2, 2, generator=g)}
+    out = D.broadcast_state_dict(sd, src=0, device=dev)
+    lo, hi = D.shard_range(46, r, w)
+    tot = D.sum_over_ranks(hi - lo, dev)
+    mx = D.max_over_ranks(float(r + 1), dev)
+    D.barrier()
+    q.put((r, {k: (str(v.dtype), v.cpu().numpy()) for k, v in out.items()}, (lo, hi), tot, mx))
+
+
+def test_broadcast_and_sharding_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(5)
+    ref = {"a.weight": torch.randn(7, 3, generator=g), "b.bias": torch.randn(5, generator=g),
+           "tab._cdf": torch.arange(12, dtype=torch.int32).reshape(3, 4), "c.weight": torch.randn(2, 2, 2, generator=g)}
+    for r, sd, rng, tot, mx in res:
+        assert list(sd) == list(ref)
+        for k in ref:
+            assert sd[k][0] == str(ref[k].dtype) and (sd[k][1] == ref[k].numpy()).all(), (r, k)
+        assert tot == 46 and mx == 2.0
+    assert res[0][2] == (0, 23) and res[1][2] == (23, 46)
+
+
+def test_shard_plan_46_clips_over_8():
+    sys.path.insert(0, REPO)
+    import evc_amd  # noqa: F401
+    from evc_amd.dist import shard_range
+    sizes = [shard_range(46, r, 8) for r in range(8)]
+    assert [b - a for a, b in sizes] == [6, 6, 6, 6, 6, 6, 5, 5]
+    assert sizes[0][0] == 0 and sizes[-1][1] == 46 and all(sizes[i][1] == sizes[i + 1][0] for i in range(7))
+    assert shard_range(3, 5, 8) == (3, 3)   # more ranks than items: empty shard

@@ -1,0 +1,84 @@
+"""GPU parity tests for the ELIC key-frame codec (HIP) against the CPU oracle restatement.
+
+Integer symbols must be exact.  Float tensors are compared with the symbols TEACHER-FORCED into the oracle:
+two float pipelines (CPU torch vs HIP) differ by ~1e-6, which can flip a predicted scale across a CDF-bin edge
+and desynchronise an arithmetic decoder -- inherent to learned codecs across devices, so cross-device decoding
+of the same bytes is not asserted; same-device encode->decode is, bit-exactly."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rnd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import evc_amd  # noqa: F401
+    from evc_amd import synthetic
+    from evc_amd.elic import ElicModel
+    sd = synthetic.elic_state_dict(21)
+    frames = synthetic.make_clips(1, seed=3, frames=3, size=128)[0].astype(np.float32) / 255
+    return sd, ElicModel(sd), torch.from_numpy(frames)
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def test_encode_decode_symbols_exact_and_batch_independent(setup):
+    sd, model, x = setup
+    enc = model.compress(x, return_latents=True)
+    assert enc["shape"] == (2, 2) and len(enc["strings"][0]) == 5 and len(enc["strings"][1]) == 3
+    dec = model.decompress(enc["strings"], enc["shape"], return_latents=True)
+    assert torch.equal(dec["y_hat"], enc["y_hat"])                      # decoder == encoder latents, bitwise
+    assert float((enc["y_hat"] - enc["y"]).abs().max()) <= 0.5 + 1e-4  # rounding residual
+    assert dec["x_hat"].shape == (3, 3, 128, 128)
+    assert float(dec["x_hat"].min()) >= 0.0 and float(dec["x_hat"].max()) <= 1.0
+    # decode frame 1 alone: same bytes -> bit-identical pixels (no dependence on batch composition)
+    ys = [[[p[1]] for p in sl] for sl in enc["strings"][0]]
+    one = model.decompress([ys, [enc["strings"][1][1]]], enc["shape"])
+    assert torch.equal(one["x_hat"][0], dec["x_hat"][1])
+    # encoding frame 1 alone gives the same bytes as inside the batch
+    enc1 = model.compress(x[1:2])
+    assert enc1["strings"][1][0] == enc["strings"][1][1]
+    assert all(enc1["strings"][0][i][p][0] == enc["strings"][0][i][p][1] for i in range(5) for p in range(2))
+
+
+def test_against_oracle_with_teacher_forced_symbols(setup):
+    from evc_amd import lib
+    from oracle import elic as OEL
+    sd, model, x = setup
+    x = x[:2]
+    enc = model.compress(x, return_latents=True)
+    dec = model.decompress(enc["strings"], enc["shape"], return_latents=True)
+    # analysis transform (encoder side) against the oracle
+    assert rel(enc["y"], OEL.g_a(sd, x)) < 2e-4
+
+    class Forced:
+        """z strings are really decoded (integer path); y symbols are the ones the HIP decoder produced."""
+        def __init__(self):
+            self.queue = [s[b] for s in dec["symbols"] for b in range(s.shape[0])]
+            self.z_left = 2
+
+        def decode_with_indexes(self, s, idx, cdf, size, off):
+            if self.z_left > 0:
+                self.z_left -= 1
+                return lib.rans_decode(s, idx, cdf, size, off)
+            return self.queue.pop(0).reshape(-1)
+    ref = OEL.decompress(sd, enc["strings"], enc["shape"], coder=Forced(), return_latents=True)
+    assert torch.equal(ref["z_hat"], dec["z_hat"].cpu())        # integer z path: exact
+    assert rel(dec["y_hat"], ref["y_hat"]) < 1e-4               # symbols + predicted means
+    assert rel(dec["x_hat"], ref["x_hat"]) < 5e-4               # synthesis transform g_s, fp32 tolerance
+
+
+def test_inference_wrapper_pad_crop_and_bits(setup):
+    from evc_amd.elic import count_bits, inference
+    sd, model, x = setup
+    img = x[0][:, :100, :120]
+    x_hat, bits = inference(model, img, patch=64)
+    assert x_hat.shape == (1, 3, 100, 120) and bits > 0 and bits % 32 == 0
+    enc = model.compress(torch.nn.functional.pad(img[None], (0, 8, 0, 28)))
+    assert bits == count_bits(enc["strings"])
