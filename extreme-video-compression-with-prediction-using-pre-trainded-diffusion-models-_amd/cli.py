@@ -1,0 +1,177 @@
+"""Command line with the reference's surface (city_sender.py:47-223, 467-617): same flags, same
+``configs/mine.yml`` schema and ``--config_mod`` grammar, same checkpoint layouts, same output file names.
+
+    python city_sender.py --data_npy data_npy/city_bonn.npy --output_path out/ --start_idx 0 --end_idx 8
+
+Differences, all additive: ``--q`` selects ELIC quality indexes (the reference hard-codes 4 and 5,
+city_sender.py:504), ``--sampler DDPM|DDIM|FPNDM``, ``--policy mask|psnr`` (+ ``--thresholds``): the
+reference decides with LPIPS (city_sender.py:376-406), whose AlexNet backbone cannot be fetched offline, so the
+policy loop is restated with the reference's own PSNR rule (``decide_5to5``, city_sender.py:353-374) or a fixed
+transmit mask; ``--synthetic`` builds seeded stand-ins when checkpoints / data are absent.  Under
+``torch.distributed.run`` the video range is block-sharded over ranks (one GPU each).
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+DEFAULT_PATHS = [f"checkpoints/neural network/{i}.pth.tar" for i in range(6)]
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    # --- the reference's flags (city_sender.py:50-130) ---
+    p.add_argument("--config", type=str, default="configs/mine.yml", help="Path to the config file")
+    p.add_argument("--seed", type=int, default=1234, help="Random seed")
+    p.add_argument("--exp", type=str, default="checkpoints/sender", help="Path for saving running related data.")
+    p.add_argument("--ni", default=True, action="store_true", help="No interaction")
+    p.add_argument("--video_gen", default=True, action="store_true")
+    p.add_argument("-v", "--video_folder", type=str, default="arg_config")
+    p.add_argument("--subsample", type=int, default=None, help="override config.sampling.subsample")
+    p.add_argument("--ckpt", type=int, default=900000, help="Model checkpoint # to load from")
+    p.add_argument("--config_mod", nargs="*", type=str, default="model.ngf=192 model.n_head_channels=192")
+    p.add_argument("--data_npy", type=str, default="city_bonn.npy", help="data_npy path, shape = B, T, C, H, W")
+    p.add_argument("--output_path", type=str, default="test_out/", help="result output path")
+    p.add_argument("-c", "--entropy-coder", choices=["ans"], default="ans", help="entropy coder")
+    p.add_argument("--cuda", default=True, help="enable the GPU (always on: there is no CPU path)")
+    p.add_argument("--plot", default=True, help="kept for compatibility (RD plots are out of scope)")
+    p.add_argument("--entropy-estimation", action="store_true")
+    p.add_argument("-p", "--path", dest="paths", type=str, nargs="+", default=DEFAULT_PATHS, help="ELIC checkpoints")
+    p.add_argument("--patch", type=int, default=64, help="padding patch size")
+    p.add_argument("--start_idx", type=int, default=0, help="Start video index")
+    p.add_argument("--end_idx", type=int, default=0, help="End video index (inclusive, city_sender.py:495)")
+    # --- additions ---
+    p.add_argument("--q", type=int, nargs="+", default=[4, 5], help="ELIC quality indexes (reference loop: 4 5)")
+    p.add_argument("--sampler", default="DDPM", choices=["DDPM", "DDIM", "FPNDM"])
+    p.add_argument("--policy", default="mask", choices=["mask", "psnr"])
+    p.add_argument("--thresholds", type=float, nargs="+", default=None,
+                   help="psnr policy: dB thresholds (reference sweeps LPIPS 0.30..0.03, city_sender.py:508)")
+    p.add_argument("--synthetic", action="store_true", help="seeded stand-ins for missing checkpoints / data")
+    return p
+
+
+def cal_psnr(a, b, maxvalue=1.0):
+    """city_sender.py:257-260."""
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return 10 * np.log10((maxvalue ** 2) / mse)
+
+
+def save_output(gt, xge, q, thr, idx, output_dir):
+    """function.py:41-52 (npy always; png when PIL is importable -- the reference uses cv2)."""
+    os.makedirs(output_dir, exist_ok=True)
+    output = np.concatenate([gt, xge], axis=0)
+    np.save(os.path.join(output_dir, "city_output_npy_idx%d_q%d_thr%.2f.npy" % (idx, q, thr)), output)
+    try:
+        from PIL import Image
+        Image.fromarray((output * 255).astype(np.uint8)).save(
+            os.path.join(output_dir, "city_idx%d_q%d_thr%.2f.png" % (idx, q, thr)))
+    except Exception:
+        pass
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    import yaml
+    from . import ckpt, config as C, dist as D, lib as L, sampler as S, synthetic
+    from .decoder import ClipDecoder
+    from .elic import ElicModel, inference
+    from .scorenet import ScoreNet
+
+    cfg, raw = C.load_config(args.config, args.config_mod)
+    if args.subsample is not None:
+        cfg.sampling.subsample = args.subsample
+    cfg.sampling.ckpt_id = args.ckpt or cfg.sampling.ckpt_id
+    rank, world, device = D.init()
+    L.hip_lib()
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    vf = os.path.join(args.exp, "video_samples", args.video_folder)
+    if rank == 0:
+        os.makedirs(vf, exist_ok=True)
+        with open(os.path.join(vf, "config.yml"), "w") as f:
+            yaml.dump(raw, f, default_flow_style=False)
+        with open(os.path.join(vf, "args.yml"), "w") as f:
+            yaml.dump(vars(args), f, default_flow_style=False)
+
+    # ---- weights: rank 0 reads (or synthesises) them, one RCCL broadcast each ----
+    sd_d, sd_e = None, {}
+    if rank == 0:
+        ck = os.path.join(args.exp, f"checkpoint_{cfg.sampling.ckpt_id}.pt")
+        if os.path.exists(ck):
+            sd_d = ckpt.load_diffusion_checkpoint(ck, ema=cfg.model.ema)
+        elif args.synthetic:
+            sd_d = synthetic.diffusion_state_dict(cfg, args.seed)
+        else:
+            sys.exit(f"missing {ck} (pass --synthetic for seeded stand-in weights)")
+        for q in args.q:
+            pth = args.paths[q]
+            if os.path.exists(pth):
+                sd_e[q] = ckpt.load_elic_state_dict(pth)
+            elif args.synthetic:
+                sd_e[q] = synthetic.elic_state_dict(q)
+            else:
+                sys.exit(f"missing {pth} (pass --synthetic)")
+    sd_d = D.broadcast_state_dict(sd_d, 0, device, world)
+    net = ScoreNet(cfg, sd_d, device=device)
+    models = {q: ElicModel(D.broadcast_state_dict(sd_e.get(q), 0, device, world), device=device) for q in args.q}
+
+    if os.path.exists(args.data_npy):
+        data = np.load(args.data_npy, mmap_mode="r")
+    elif args.synthetic:
+        data = synthetic.make_clips(args.end_idx + 1, seed=args.seed)
+    else:
+        sys.exit(f"missing {args.data_npy} (pass --synthetic)")
+
+    lo, hi = D.shard_range(args.end_idx + 1 - args.start_idx, rank, world)
+    gen = torch.Generator(device=device).manual_seed(args.seed + rank)
+    thresholds = args.thresholds if args.policy == "psnr" and args.thresholds else [0.0]
+    t_start = time.time()
+    for vid in range(args.start_idx + lo, args.start_idx + hi):
+        out_root = os.path.join(args.output_path, f"output_{vid}")
+        gt = torch.from_numpy(np.asarray(data[vid], dtype=np.float32) / 255.0)          # (30,3,H,W)
+        all_psnr, all_bpp = [], []
+        for q in args.q:
+            model = models[q]
+            dec = ClipDecoder(net, model, cfg, S.get_sampler(args.sampler))
+            for thr in thresholds:
+                x_ge, bits, d = [], [], []
+                for f in (0, 1):                                    # key frames (city_sender.py:521-524)
+                    xh, b = inference(model, gt[f].to(device), args.patch)
+                    x_ge.append(xh[0]); bits.append(b); d.append(1)
+                while len(x_ge) < 30:                                # city_sender.py:534-548
+                    l = len(x_ge)
+                    cond = torch.stack(x_ge[-2:], 0)[None]
+                    pred = dec.generate(cond.contiguous(), generator=gen)[0]
+                    acc = 0
+                    for j in range(min(5, 30 - l)):
+                        ok = args.policy == "mask" or cal_psnr(pred[j].cpu().numpy(), gt[l + j].numpy()) >= thr
+                        if not ok:
+                            break
+                        x_ge.append(pred[j]); d.append(0); acc += 1
+                    if acc == 0:
+                        for f in (l, l + 1):
+                            if f < 30:
+                                xh, b = inference(model, gt[f].to(device), args.patch)
+                                x_ge.append(xh[0]); bits.append(b); d.append(1)
+                x = torch.stack(x_ge[:30], 0).cpu().numpy()
+                bpp = sum(bits) / 128 / 128 / 30
+                ps = [cal_psnr(x[i], gt[i].numpy()) for i in range(30)]
+                print(f"[rank {rank}] video {vid} q{q} thr {thr:.2f}: d={d[:30]} BPP {bpp:.5f} PSNR {np.mean(ps):.3f}",
+                      flush=True)
+                all_psnr.append(ps); all_bpp.append(bpp)
+                g = np.concatenate(list(gt.numpy().transpose(0, 2, 3, 1)), axis=1)
+                xg = np.concatenate(list(x.transpose(0, 2, 3, 1)), axis=1)
+                save_output(g, xg, q, thr, vid, out_root)
+        os.makedirs(out_root, exist_ok=True)
+        np.save(os.path.join(out_root, f"psnr_{vid}.npy"), np.asarray(all_psnr))
+        np.save(os.path.join(out_root, f"bpp_{vid}.npy"), np.asarray(all_bpp))
+    D.barrier()
+    if rank == 0:
+        print(f"done in {time.time() - t_start:.1f}s")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,82 @@
+"""CPU tests of the host-side mirror of the reference interface: config grammar, checkpoint layouts, CLI flags,
+module program, and that compute entry points fail loudly without a GPU (no fallback)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import evc_amd  # noqa: F401
+from evc_amd import ckpt, cli, config as C, lib, scorenet, synthetic
+from oracle import scorenet as OS
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_loads_and_config_mod_grammar():
+    cfg, raw = C.load_config(os.path.join(REPO, "configs", "mine.yml"), "model.ngf=64 model.n_head_channels=64 "
+                             "sampling.subsample=50 model.attn_resolutions=[8,16] model.version=DDIM")
+    assert cfg.model.ngf == 64 and cfg.sampling.subsample == 50 and cfg.model.attn_resolutions == [8, 16]
+    assert cfg.model.version == "DDIM"                      # string targets stay strings (city_sender.py:151-152)
+    assert cfg.data.num_frames == 5 and cfg.data.num_frames_cond == 2 and cfg.model.arch == "unetmore"
+    d = C.namespace2dict(C.default_config())
+    _, raw = C.load_config(os.path.join(REPO, "configs", "mine.yml"))
+    for sec in ("sampling", "data", "model"):
+        for k, v in d[sec].items():
+            assert raw[sec][k] == v or k in ("ngf", "n_head_channels", "subsample"), (sec, k)
+
+
+def test_module_program_matches_oracle_and_reference_counts():
+    cfg = C.default_config()
+    prog = scorenet.build_program(scorenet.dims_from_config(cfg))
+    ref = OS.program(OS.Dims())
+    assert len(prog) == len(ref) == 50
+    kinds = [m["kind"] for m in prog]
+    assert kinds.count("res") == 35 and kinds.count("attn") == 10
+    for a, b in zip(prog, ref):
+        if a["kind"] == "res":
+            assert (a["cin"], a["cout"], a["up"], a["down"]) == (b["cin"], b["cout"], b["up"], b["down"])
+    n = sum(int(np.prod(s)) for _, s in synthetic.diffusion_param_shapes(cfg))
+    assert n == 262_133_775 - 0                                # parameter count of the reference net
+
+
+def test_diffusion_checkpoint_layout_roundtrip(tmp_path):
+    cfg = C.default_config(32, 32, 32)
+    sd = synthetic.diffusion_state_dict(cfg, 3)
+    ema = {k: v + 1.0 for k, v in sd.items()}
+    states = ckpt.make_diffusion_states(sd, ema)
+    assert all(k.startswith("module.") for k in states[0]) and isinstance(states, list)
+    path = tmp_path / "checkpoint_900000.pt"
+    torch.save(states, path)
+    with_ema = ckpt.load_diffusion_checkpoint(str(path), ema=True)
+    no_ema = ckpt.load_diffusion_checkpoint(str(path), ema=False)
+    k = "unet.all_modules.3.Conv_0.weight"
+    assert torch.equal(with_ema[k], sd[k] + 1.0) and torch.equal(no_ema[k], sd[k])
+
+
+def test_elic_state_dict_normalisation_and_shapes():
+    sd = synthetic.elic_state_dict(5)
+    legacy = {"module." + k: v for k, v in sd.items()}
+    legacy["module.entropy_bottleneck._matrices.0"] = torch.zeros(3)
+    out = ckpt.normalise_elic_state_dict(legacy)
+    assert "entropy_bottleneck._matrix0" in out and "g_s.1.weight" in out
+    assert sd["g_s.1.weight"].shape == (320, 192, 5, 5) and sd["g_s.14.weight"].shape == (192, 3, 5, 5)
+    assert sd["ParamAggregation.4.0.weight"].shape == (640, 1408, 1, 1)
+    assert sd["cc_transforms.3.0.weight"].shape == (224, 80, 5, 5)
+    assert sd["gaussian_conditional._quantized_cdf"].shape[0] == 64
+
+
+def test_cli_keeps_reference_flags():
+    a = cli.build_parser().parse_args(["--data_npy", "x.npy", "--output_path", "o", "--start_idx", "0", "--end_idx", "8",
+                                       "--ckpt", "900000", "-p", "a", "b", "--patch", "64", "-c", "ans"])
+    assert a.end_idx == 8 and a.paths == ["a", "b"] and a.config == "configs/mine.yml" and a.seed == 1234
+    assert a.config_mod == "model.ngf=192 model.n_head_channels=192" and a.exp == "checkpoints/sender"
+
+
+def test_compute_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU visible")
+    with pytest.raises(lib.EvcLibraryError):
+        lib.hip_lib()
+    with pytest.raises(lib.EvcLibraryError):
+        scorenet.ScoreNet(C.default_config(32, 32, 32), {}, device="cpu")
