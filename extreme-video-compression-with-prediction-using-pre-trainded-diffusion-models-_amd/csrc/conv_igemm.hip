@@ -4,13 +4,25 @@
 //
 // GEMM view: M = B*H*W output pixels (A operand, gathered from NHWC activations), N = Co (B operand,
 // pre-packed weights), K = KH*KW*Ci walked in steps of KC = 16 channels of one tap.
-// One workgroup = 4 waves (2 x 2) computes a 128 x (64*TN) tile with v_mfma_f32_32x32x2_f32
-// (exact f32: bitwise a k-ordered fmaf chain); each wave owns 64 pixels x 32*TN channels.
-// Per step the A tile [128][16] and W tile [64*TN][16] are prefetched global -> registers while the
-// previous step's MFMAs run, transformed (GroupNorm affine + SiLU/ReLU, zero padding after the
-// activation) and written to the other LDS buffer: one barrier per step.
-// LDS rows are padded to 20 floats so the ds_read_b128 fragment reads (4 k-values per lane: lanes
-// 0-31 take k 0..3, lanes 32-63 take k 4..7 of each 8-deep group) are bank-conflict free.
+// One workgroup = 4 waves (2 x 2) computes a 128 x (64*TN) tile with v_mfma_f32_32x32x2_f32 (exact f32:
+// bitwise a k-ordered fmaf chain); each wave owns 64 pixels x 32*TN channels (6 accumulator tiles at TN=3).
+//
+// Per K-step, for the NEXT step:
+//   * W slab [64*TN][16] goes global -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPRs, no ds_write;
+//     the packed weights are stored pre-swizzled, so a linear copy lands in the conflict-free layout;
+//   * A tile [128][16] goes global -> registers (2 float4 per thread), is transformed in registers
+//     (GroupNorm affine + SiLU/ReLU; out-of-image taps are zeroed by a select AFTER the activation,
+//     which is what zero padding of the activated tensor means) and written to LDS between the second
+//     half of the MFMAs.  Addresses are 32-bit offsets advanced incrementally (no divisions in the loop);
+//     tap validity is a per-thread bit mask built once; affine coefficients reload only when the channel
+//     chunk changes.
+// The K-step is straight-line code with one barrier.  LDS tiles are unpadded 64-byte rows with the 16-byte
+// chunk index XOR-ed by (row >> 2) & 3: every ds_read_b128 fragment read (lanes 0-31 take k 0..3, lanes 32-63
+// k 4..7 of each 8-deep group) and every ds_write_b128 is bank-conflict free.  40 KB LDS per workgroup.
+//
+// Measured on MI355X (tools/conv_bench.hip): the MFMA + fragment-read + barrier skeleton alone reaches ~130
+// TFLOP/s at the ~2.18 GHz the chip holds under this load (fp32 roof 157.3 at 2.4 GHz); every producer
+// instruction costs issue slots, which is why the producer side is kept this thin.
 //
 // Replaces nn.Conv2d 3x3/1x1 (reference models/better/layers.py:89-113), NIN (layers.py:535-544),
 // nn.Linear (ncsnpp_more.py:89-95, layerspp.py:507) and the ELIC conv stacks (Network.py:106-166).
@@ -19,16 +31,20 @@
 #include "../../include/evc_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
 
 namespace {
 
 constexpr int BM = 128;      // pixels per workgroup tile
-constexpr int KC = 16;       // channels per K step
-constexpr int LDS_LD = 20;   // padded LDS row (floats)
+constexpr int KC = 16;       // channels per K step (one 64-byte LDS row)
+
+// load-transform modes (template parameter of the kernel)
+constexpr int MODE_PLAIN = 0, MODE_AFFINE = 1, MODE_AFFINE_SILU = 2, MODE_SILU = 3, MODE_RELU = 4;
 
 struct ConvK {
     const float* src0; const float* src1; int C0; int C1; int ld0; int ld1;
-    const float* coef_a; const float* coef_s; int act_in;
+    const float* coef_a; const float* coef_s;
     const float* w; const float* bias; const float* res; int ld_res;
     float out_scale; int act_out;
     float* out; int ld_out;
@@ -37,19 +53,46 @@ struct ConvK {
     float* ws;   // split-K slabs [splits][M][Co] when splits > 1
 };
 
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
 __device__ __forceinline__ float act_fn(float v, int act) {
-    if (act == EVC_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+    if (act == EVC_ACT_SILU) return silu_f(v);
     if (act == EVC_ACT_RELU) return fmaxf(v, 0.0f);
     return v;
 }
 
+template <int MODE>
+__device__ __forceinline__ float4 transform(float4 v, const float4& a, const float4& s, bool ok) {
+    if (MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU) {
+        v.x = v.x * a.x + s.x; v.y = v.y * a.y + s.y; v.z = v.z * a.z + s.z; v.w = v.w * a.w + s.w;
+    }
+    if (MODE == MODE_AFFINE_SILU || MODE == MODE_SILU) {
+        v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w);
+    }
+    if (MODE == MODE_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    return v;
+}
+
+// 4 k-pairs x 2 x TN MFMAs on one 8-deep k group; consecutive MFMAs go to different accumulators.
 template <int TN>
+__device__ __forceinline__ void mfma_group(f32x16 (&acc)[2][TN], const float4 (&a)[2], const float4 (&b)[TN]) {
+#define EVC_MFMA_E(e)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)       \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].e, b[j].e, acc[i][j], 0, 0, 0);
+    EVC_MFMA_E(x) EVC_MFMA_E(y) EVC_MFMA_E(z) EVC_MFMA_E(w)
+#undef EVC_MFMA_E
+}
+
+template <int TN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     constexpr int BN = 64 * TN;
-    constexpr int WLOADS = BN / 64;   // float4 weight loads per thread per step
+    constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const As = smem;                        // [2][BM][LDS_LD]
-    float* const Ws = smem + 2 * BM * LDS_LD;      // [2][BN][LDS_LD]
+    float* const As = smem;                    // [2][BM][16]
+    float* const Ws = smem + 2 * BM * KC;      // [2][BN][16]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -63,82 +106,97 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     const int s_begin = split * p.steps_per_split;
     const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
 
-    // ---- per-thread gather bookkeeping: two A rows (r, r + 64), one 4-channel column k4 ----
+    // ---- per-thread gather state: rows r0 = tid/4 and r0 + 64, 4-channel column k4 ----
     const int k4 = tid & 3;
     const int padH = p.KH >> 1, padW = p.KW >> 1;
-    const int taps = p.KH * p.KW;
-    int rb[2], ry[2], rx[2];
-    bool rvalid[2];
+    const int Ct = p.C0 + p.C1;
+    unsigned off0[2], off1[2], okmask[2];     // byte offsets of the output pixel in src0 / src1, tap-valid bits
+    int rb[2], a_lds[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        int m = m0 + (tid >> 2) + 64 * i;
-        rvalid[i] = m < p.M;
-        int mm = rvalid[i] ? m : 0;
-        int b = mm / p.HW;
-        int rem = mm - b * p.HW;
-        int y = rem / p.W;
-        rb[i] = b; ry[i] = y; rx[i] = rem - y * p.W;
+        const int row = (tid >> 2) + 64 * i;
+        const int m = m0 + row;
+        const bool valid = m < p.M;
+        const int mm = valid ? m : 0;
+        const int b = mm / p.HW;
+        const int rem = mm - b * p.HW;
+        const int y = rem / p.W;
+        const int x = rem - y * p.W;
+        rb[i] = b;
+        off0[i] = ((unsigned)mm * (unsigned)p.ld0 + 4u * k4) * 4u;
+        off1[i] = ((unsigned)mm * (unsigned)p.ld1 + 4u * k4) * 4u;
+        unsigned mask = 0;
+        for (int ty = 0; ty < p.KH; ++ty)
+            for (int tx = 0; tx < p.KW; ++tx) {
+                const int yy = y + ty - padH, xx = x + tx - padW;
+                const bool ok = valid && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                mask |= (ok ? 1u : 0u) << (ty * p.KW + tx);
+            }
+        okmask[i] = mask;
+        a_lds[i] = row * KC + 4 * (k4 ^ ((row >> 2) & 3));        // swizzled float offset inside an A buffer
     }
-    const int Ct = p.C0 + p.C1;
-    const bool has_coef = p.coef_a != nullptr;
 
-    float4 areg[2], ca[2], cs[2], wreg[WLOADS];
+    // fragment read offsets (floats): chunk c = 2*kk + half sits at position c ^ ((row >> 2) & 3); tile and
+    // wave row offsets are multiples of 16 rows, so the XOR term depends on the lane only.
+    const int fsw = (l31 >> 2) & 3;
+    const int rd0 = 4 * ((0 + half) ^ fsw), rd1 = 4 * ((2 + half) ^ fsw);
+    const int a_rd = (wm * 64 + l31) * KC, w_rd = (wn * 32 * TN + l31) * KC;
+
+    // ---- "next step" cursor, advanced incrementally (chunk-major, taps inner) ----
+    int c_chunk, c_ty, c_tx;
+    {
+        const int taps = p.KH * p.KW;
+        c_chunk = s_begin / taps;
+        const int tap = s_begin - c_chunk * taps;
+        c_ty = tap / p.KW;
+        c_tx = tap - c_ty * p.KW;
+    }
+    float4 areg[2], ca[2], cs[2];
     bool aok[2];
 
-    auto issue_loads = [&](int s) {
-        const int chunk = s / taps;
-        const int tap = s - chunk * taps;
-        const int dy = tap / p.KW - padH;
-        const int dx = tap - (tap / p.KW) * p.KW - padW;
-        const int c = chunk * KC;
-        const float* src; int cs_off, Csrc;
-        if (c < p.C0) { src = p.src0; cs_off = c; Csrc = p.ld0; }
-        else { src = p.src1; cs_off = c - p.C0; Csrc = p.ld1; }
+    auto load_coefs = [&]() {
+        if (HAS_COEF) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int yy = ry[i] + dy, xx = rx[i] + dx;
-            aok[i] = rvalid[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-            if (aok[i]) {
-                const size_t off = ((size_t)(rb[i] * p.H + yy) * p.W + xx) * Csrc + cs_off + 4 * k4;
-                areg[i] = *reinterpret_cast<const float4*>(src + off);
-                if (has_coef) {
-                    const size_t co = (size_t)rb[i] * Ct + c + 4 * k4;
-                    ca[i] = *reinterpret_cast<const float4*>(p.coef_a + co);
-                    cs[i] = *reinterpret_cast<const float4*>(p.coef_s + co);
-                }
-            } else {
-                areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < 2; ++i) {
+                const size_t co = (size_t)rb[i] * Ct + c_chunk * KC + 4 * k4;
+                ca[i] = *reinterpret_cast<const float4*>(p.coef_a + co);
+                cs[i] = *reinterpret_cast<const float4*>(p.coef_s + co);
             }
         }
-        const float* wt = p.w + ((size_t)(tap * p.nchunk + chunk) * p.CoPad + n0) * KC;
-#pragma unroll
-        for (int j = 0; j < WLOADS; ++j)
-            wreg[j] = *reinterpret_cast<const float4*>(wt + (size_t)(tid + 256 * j) * 4);
     };
-
-    auto store_tiles = [&](int buf) {
-        float* A = As + buf * BM * LDS_LD;
-        float* Wl = Ws + buf * BN * LDS_LD;
+    // Issue the operand fetches of the step the cursor points at: A -> registers, W -> LDS buffer `buf` by DMA.
+    auto issue_loads = [&](int buf) {
+        const int c = c_chunk * KC;
+        const bool first = c < p.C0;                              // wave-uniform
+        const char* src = reinterpret_cast<const char*>(first ? p.src0 : p.src1);
+        const int ld = first ? p.ld0 : p.ld1;
+        const int tap = c_ty * p.KW + c_tx;
+        // uniform byte delta of this (tap, chunk) relative to the output pixel's channel 0
+        const int delta = (((c_ty - padH) * p.W + (c_tx - padW)) * ld + (first ? c : c - p.C0)) * 4;
+        const unsigned safe = (unsigned)((first ? c : c - p.C0) + 4 * k4) * 4u;   // pixel 0: always legal
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            float4 v = areg[i];
-            if (aok[i]) {
-                if (has_coef) {
-                    v.x = v.x * ca[i].x + cs[i].x; v.y = v.y * ca[i].y + cs[i].y;
-                    v.z = v.z * ca[i].z + cs[i].z; v.w = v.w * ca[i].w + cs[i].w;
-                }
-                if (p.act_in != EVC_ACT_NONE) {
-                    v.x = act_fn(v.x, p.act_in); v.y = act_fn(v.y, p.act_in);
-                    v.z = act_fn(v.z, p.act_in); v.w = act_fn(v.w, p.act_in);
-                }
-            }
-            *reinterpret_cast<float4*>(A + ((tid >> 2) + 64 * i) * LDS_LD + 4 * k4) = v;
+            aok[i] = (okmask[i] >> tap) & 1u;
+            const unsigned o = aok[i] ? (first ? off0[i] : off1[i]) + (unsigned)delta : safe;
+            areg[i] = *reinterpret_cast<const float4*>(src + o);
         }
+        const float* wt = p.w + ((size_t)(tap * p.nchunk + c_chunk) * p.CoPad + n0) * KC;
+        float* wl = Ws + buf * BN * KC;
 #pragma unroll
-        for (int j = 0; j < WLOADS; ++j) {
-            const int idx = tid + 256 * j;
-            *reinterpret_cast<float4*>(Wl + (idx >> 2) * LDS_LD + 4 * (idx & 3)) = wreg[j];
-        }
+        for (int j = 0; j < TN; ++j)     // one wave instruction moves 16 rows (1 KiB); 4 waves x TN rounds
+            __builtin_amdgcn_global_load_lds((glb_void*)(wt + (size_t)(tid + 256 * j) * 4),
+                                             (lds_void*)(wl + (wave * 16 + 64 * j) * KC), 16, 0, 0);
+    };
+    auto advance = [&]() {
+        ++c_tx;
+        if (c_tx == p.KW) { c_tx = 0; ++c_ty; }
+        if (c_ty == p.KH) { c_ty = 0; ++c_chunk; }
+    };
+    auto store_a = [&](int buf) {
+        float* A = As + buf * BM * KC;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<float4*>(A + a_lds[i]) = transform<MODE>(areg[i], ca[i], cs[i], aok[i]);
     };
 
     f32x16 acc[2][TN];
@@ -150,61 +208,97 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (s_begin < s_end) {
-        issue_loads(s_begin);
-        store_tiles(0);
+        load_coefs();
+        issue_loads(0);
+        store_a(0);
     }
     __syncthreads();
 
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
-        const bool more = (s + 1) < s_end;
-        if (more) issue_loads(s + 1);
-
-        const float* Ab = As + buf * BM * LDS_LD + (wm * 64 + l31) * LDS_LD + 4 * half;
-        const float* Wb = Ws + buf * BN * LDS_LD + (wn * 32 * TN + l31) * LDS_LD + 4 * half;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            float4 a[2], b[TN];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + kk * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * LDS_LD + kk * 8);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                }
+        // Always prefetch: the last iteration re-fetches its own step into the idle buffers, which keeps the
+        // body free of data-dependent control flow.
+        if (s + 1 < s_end) {
+            const int prev_chunk = c_chunk;
+            advance();
+            if (HAS_COEF && c_chunk != prev_chunk) load_coefs();      // wave-uniform, once per KH*KW steps
         }
-        if (more) store_tiles(buf ^ 1);
-        __syncthreads();
+        issue_loads(buf ^ 1);
+
+        const float* Ab = As + buf * BM * KC + a_rd;
+        const float* Wb = Ws + buf * BN * KC + w_rd;
+        float4 a0[2], b0[TN], a1[2], b1[TN];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a0[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * KC + rd0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b0[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * KC + rd0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a1[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * KC + rd1);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b1[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * KC + rd1);
+        mfma_group<TN>(acc, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        store_a(buf ^ 1);            // producer work for the next step sits among the second half of the MFMAs
+        mfma_group<TN>(acc, a1, b1);
+        __syncthreads();             // also drains the W DMA (vmcnt) before anyone reads the new buffers
     }
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
     const bool partial = p.splits > 1;
+    const int mw = m0 + wm * 64 + 4 * half;
+    const int cw = n0 + wn * 32 * TN + l31;
+    if (m0 + BM <= p.M && n0 + BN <= p.Co) {
+        // full tile: straight-line code, residual loads batched ahead of the arithmetic
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int co = n0 + wn * 32 * TN + j * 32 + l31;
-        if (co >= p.Co) continue;
-        const float bias = (!partial && p.bias) ? p.bias[co] : 0.f;
+        for (int j = 0; j < TN; ++j) {
+            const int co = cw + j * 32;
+            const float bias = (!partial && p.bias) ? p.bias[co] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r];
+            for (int i = 0; i < 2; ++i) {
+                const int mb = mw + i * 32;
                 if (partial) {
-                    p.ws[((size_t)split * p.M + m) * p.Co + co] = v;
+                    float* o = p.ws + ((size_t)split * p.M + mb) * p.Co + co;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * p.Co] = acc[i][j][r];
                 } else {
-                    v += bias;
-                    if (p.res) v += p.res[(size_t)m * p.ld_res + co];
-                    v *= p.out_scale;
-                    v = act_fn(v, p.act_out);
-                    p.out[(size_t)m * p.ld_out + co] = v;
+                    float rv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+                    if (p.res) {
+                        const float* rp = p.res + (size_t)mb * p.ld_res + co;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) rv[r] = rp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ld_res];
+                    }
+                    float* o = p.out + (size_t)mb * p.ld_out + co;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = (acc[i][j][r] + bias + rv[r]) * p.out_scale;
+                        o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ld_out] = act_fn(v, p.act_out);
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int co = cw + j * 32;
+            if (co >= p.Co) continue;
+            const float bias = (!partial && p.bias) ? p.bias[co] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (m >= p.M) continue;
+                    float v = acc[i][j][r];
+                    if (partial) {
+                        p.ws[((size_t)split * p.M + m) * p.Co + co] = v;
+                    } else {
+                        v += bias;
+                        if (p.res) v += p.res[(size_t)m * p.ld_res + co];
+                        v *= p.out_scale;
+                        p.out[(size_t)m * p.ld_out + co] = act_fn(v, p.act_out);
+                    }
                 }
             }
         }
@@ -227,7 +321,7 @@ __global__ void conv_splitk_reduce_kernel(const float* ws, int splits, int M, in
     }
 }
 
-// w [Co][Ci][KH][KW] -> packed [KH*KW][Ci/16][CoPad][16] (zero rows for co >= Co).
+// w [Co][Ci][KH][KW] -> packed [KH*KW][Ci/16][CoPad][16] (zero rows for co >= Co), 16-byte chunks swizzled.
 __global__ void conv_pack_weights_kernel(const float* w, float* packed, int Co, int CoPad, int Ci, int KH, int KW) {
     const int taps = KH * KW, nchunk = Ci / KC;
     const size_t total = (size_t)taps * nchunk * CoPad * KC;
@@ -237,8 +331,11 @@ __global__ void conv_pack_weights_kernel(const float* w, float* packed, int Co, 
         const int co = (int)(t % CoPad); t /= CoPad;
         const int chunk = (int)(t % nchunk);
         const int tap = (int)(t / nchunk);
+        // LDS swizzle baked into the packed layout: physical 16-byte chunk q of row co holds logical chunk
+        // q ^ ((co >> 2) & 3), so the kernel's linear LDS-DMA copy lands conflict-free.
+        const int kl = (((k >> 2) ^ ((co >> 2) & 3)) << 2) | (k & 3);
         float v = 0.f;
-        if (co < Co) v = w[((size_t)co * Ci + chunk * KC + k) * taps + tap];
+        if (co < Co) v = w[((size_t)co * Ci + chunk * KC + kl) * taps + tap];
         packed[i] = v;
     }
 }
@@ -308,18 +405,43 @@ extern "C" long long evc_conv_workspace_bytes(const evc_conv_args* a) {
     return (long long)s * a->B * a->H * a->W * a->Co * (long long)sizeof(float);
 }
 
+extern "C" int evc_conv_set_wave_layout(int) { return EVC_OK; }   // retired tuning hook (kept for ABI stability)
+
+template <int TN>
+static void launch_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+    switch (mode) {
+        case MODE_AFFINE: hipLaunchKernelGGL((conv_igemm_kernel<TN, MODE_AFFINE>), grid, dim3(256), lds, st, k); break;
+        case MODE_AFFINE_SILU: hipLaunchKernelGGL((conv_igemm_kernel<TN, MODE_AFFINE_SILU>), grid, dim3(256), lds, st, k); break;
+        case MODE_SILU: hipLaunchKernelGGL((conv_igemm_kernel<TN, MODE_SILU>), grid, dim3(256), lds, st, k); break;
+        case MODE_RELU: hipLaunchKernelGGL((conv_igemm_kernel<TN, MODE_RELU>), grid, dim3(256), lds, st, k); break;
+        default: hipLaunchKernelGGL((conv_igemm_kernel<TN, MODE_PLAIN>), grid, dim3(256), lds, st, k); break;
+    }
+}
+
 extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stream) {
     int rc = conv_validate(a);
     if (rc != EVC_OK) return rc;
+    int mode;
+    if (a->coef_a) {
+        if (a->act_in == EVC_ACT_SILU) mode = MODE_AFFINE_SILU;
+        else if (a->act_in == EVC_ACT_NONE) mode = MODE_AFFINE;
+        else return EVC_EUNSUPPORTED;
+    } else {
+        mode = a->act_in == EVC_ACT_SILU ? MODE_SILU : a->act_in == EVC_ACT_RELU ? MODE_RELU : MODE_PLAIN;
+        if (a->act_in != EVC_ACT_NONE && a->act_in != EVC_ACT_SILU && a->act_in != EVC_ACT_RELU) return EVC_EINVAL;
+    }
     ConvK k;
-    k.src0 = a->src0; k.src1 = a->src1; k.C0 = a->C0; k.C1 = a->C1;
-    k.ld0 = a->ld0 > 0 ? a->ld0 : a->C0; k.ld1 = a->ld1 > 0 ? a->ld1 : a->C1;
-    k.coef_a = a->coef_a; k.coef_s = a->coef_s; k.act_in = a->act_in;
+    k.src0 = a->src0; k.src1 = a->src1 ? a->src1 : a->src0; k.C0 = a->C0; k.C1 = a->C1;
+    k.ld0 = a->ld0 > 0 ? a->ld0 : a->C0; k.ld1 = a->ld1 > 0 ? a->ld1 : (a->C1 > 0 ? a->C1 : k.ld0);
+    k.coef_a = a->coef_a; k.coef_s = a->coef_s;
     k.w = a->w_packed; k.bias = a->bias; k.res = a->res; k.ld_res = a->ld_res;
     k.out_scale = a->out_scale; k.act_out = a->act_out; k.out = a->out; k.ld_out = a->ld_out;
     k.B = a->B; k.H = a->H; k.W = a->W; k.Co = a->Co; k.CoPad = evc_conv_co_pad(a->Co);
     k.KH = a->KH; k.KW = a->KW;
     k.M = a->B * a->H * a->W; k.HW = a->H * a->W;
+    // 32-bit byte offsets inside the kernel: each source must stay below 4 GiB
+    if ((long long)k.M * k.ld0 * 4 >= (1LL << 32) || (long long)k.M * k.ld1 * 4 >= (1LL << 32)) return EVC_EUNSUPPORTED;
+    if (a->KH * a->KW > 32) return EVC_EUNSUPPORTED;   // tap-valid bit mask is 32 bits wide
     k.nchunk = (a->C0 + a->C1) / KC;
     k.nsteps = a->KH * a->KW * k.nchunk;
     k.splits = evc_conv_choose_splits(a);
@@ -331,11 +453,11 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     const int tn = pick_tn(k.CoPad);
     const int BN = 64 * tn;
     dim3 grid((k.M + BM - 1) / BM, k.CoPad / BN, k.splits);
-    const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    const size_t lds = (size_t)2 * (BM + BN) * KC * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (tn == 3) hipLaunchKernelGGL(conv_igemm_kernel<3>, grid, dim3(256), lds, st, k);
-    else if (tn == 2) hipLaunchKernelGGL(conv_igemm_kernel<2>, grid, dim3(256), lds, st, k);
-    else hipLaunchKernelGGL(conv_igemm_kernel<1>, grid, dim3(256), lds, st, k);
+    if (tn == 3) launch_mode<3>(mode, grid, lds, st, k);
+    else if (tn == 2) launch_mode<2>(mode, grid, lds, st, k);
+    else launch_mode<1>(mode, grid, lds, st, k);
     if (hipGetLastError() != hipSuccess) return EVC_ELAUNCH;
     if (k.splits > 1) {
         const size_t total = (size_t)k.M * k.Co;

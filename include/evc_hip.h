@@ -99,6 +99,9 @@ long long evc_conv_packed_floats(int Co, int Ci, int KH, int KW);
 /* w: [Co][Ci][KH][KW] (PyTorch Conv2d layout, device) -> packed (device). */
 int evc_conv_pack_weights_f32(const float* w, float* packed, int Co, int Ci, int KH, int KW, void* stream);
 int evc_conv_choose_splits(const evc_conv_args* a);
+/* Tuning hook: workgroup wave layout of the Co%192==0 kernel: 0 automatic, 1 = 4 waves (wave tile 64x96),
+ * 2 = 8 waves (wave tile 32x96).  Results are identical; only speed differs. */
+int evc_conv_set_wave_layout(int layout);
 long long evc_conv_workspace_bytes(const evc_conv_args* a);
 int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stream);
 

@@ -1,0 +1,62 @@
+// conv_bench.hip -- standalone A/B harness for csrc/conv_igemm.hip (not part of the library).
+// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include [-D<knob>=...] tools/conv_bench.hip -o bench_x
+// Run:    ./bench_x [layout] [iters]      prints ms and TFLOP/s for the dominant layer shapes (HIP-event timed).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../extreme-video-compression-with-prediction-using-pre-trainded-diffusion-models-_amd/csrc/conv_igemm.hip"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+struct Shape { int B, R, Ci, Co, K; int mode; };
+
+int main(int argc, char** argv) {
+    const int layout = argc > 1 ? atoi(argv[1]) : 0;
+    const int iters = argc > 2 ? atoi(argv[2]) : 10;
+    const int only = argc > 3 ? atoi(argv[3]) : -1;
+    evc_conv_set_wave_layout(layout);
+    std::vector<Shape> shapes = {{8, 128, 192, 192, 3, 0}, {8, 128, 192, 192, 3, 1}, {9, 128, 192, 192, 3, 1},
+                                 {8, 128, 384, 192, 3, 1}, {8, 64, 384, 384, 3, 0}, {8, 64, 384, 384, 3, 1},
+                                 {9, 64, 384, 384, 3, 1}, {8, 32, 576, 576, 3, 1}, {9, 16, 576, 576, 3, 1},
+                                 {9, 8, 768, 768, 3, 1}};
+    printf("# conv_bench layout=%d iters=%d\n", layout, iters);
+    for (size_t si = 0; si < shapes.size(); ++si) {
+        if (only >= 0 && (int)si != only) continue;
+        const Shape& s = shapes[si];
+        const size_t nx = (size_t)s.B * s.R * s.R * s.Ci, no = (size_t)s.B * s.R * s.R * s.Co;
+        const size_t nw = (size_t)evc_conv_packed_floats(s.Co, s.Ci, s.K, s.K);
+        float *x, *w, *o, *ca, *cs, *ws;
+        CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&o, no * 4));
+        CK(hipMalloc(&ca, (size_t)s.B * s.Ci * 4)); CK(hipMalloc(&cs, (size_t)s.B * s.Ci * 4));
+        std::vector<float> h(std::max(nx, nw));
+        for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((int)((i * 2654435761u) >> 8 & 0xffff) - 32768) / 32768.0f;
+        CK(hipMemcpy(x, h.data(), nx * 4, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < nw; ++i) h[i] *= 0.02f;
+        CK(hipMemcpy(w, h.data(), nw * 4, hipMemcpyHostToDevice));
+        std::vector<float> one((size_t)s.B * s.Ci, 1.0f), zero((size_t)s.B * s.Ci, 0.1f);
+        CK(hipMemcpy(ca, one.data(), one.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(cs, zero.data(), zero.size() * 4, hipMemcpyHostToDevice));
+        evc_conv_args a = {};
+        a.src0 = x; a.C0 = s.Ci; a.w_packed = w; a.out = o; a.ld_out = s.Co; a.out_scale = 1.f;
+        a.B = s.B; a.H = s.R; a.W = s.R; a.Co = s.Co; a.KH = s.K; a.KW = s.K;
+        if (s.mode) { a.coef_a = ca; a.coef_s = cs; a.act_in = EVC_ACT_SILU; }
+        long long wsb = evc_conv_workspace_bytes(&a);
+        ws = nullptr;
+        if (wsb > 0) CK(hipMalloc(&ws, wsb));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int i = 0; i < 2; ++i) if (evc_conv2d_nhwc_f32(&a, ws, nullptr) != 0) { printf("launch failed\n"); return 1; }
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) evc_conv2d_nhwc_f32(&a, ws, nullptr);
+        CK(hipEventRecord(e1, nullptr));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+        const double flop = 2.0 * s.B * s.R * s.R * (double)s.Ci * s.Co * s.K * s.K;
+        printf("B=%d %3dx%-3d %4d->%-4d k%d %s splits=%d : %.3f ms  %.1f TF/s\n", s.B, s.R, s.R, s.Ci, s.Co, s.K,
+               s.mode ? "gn+silu" : "plain  ", evc_conv_choose_splits(&a), ms, flop / ms / 1e9);
+        hipFree(x); hipFree(w); hipFree(o); hipFree(ca); hipFree(cs); if (ws) hipFree(ws);
+    }
+    return 0;
+}
