@@ -51,6 +51,7 @@ struct ConvK {
     int B, H, W, Co, CoPad, KH, KW;
     int M, HW, nchunk, nsteps, steps_per_split, splits;
     float* ws;   // split-K slabs [splits][M][Co] when splits > 1
+    float* stats;   // optional fused per-channel moments [M/64][Co][2]
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         for (int j = 0; j < TN; ++j) {
             const int co = cw + j * 32;
             const float bias = (!partial && p.bias) ? p.bias[co] : 0.f;
+            float st_sum = 0.f, st_sq = 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int mb = mw + i * 32;
@@ -272,9 +274,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
                     float* o = p.out + (size_t)mb * p.ld_out + co;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float v = (acc[i][j][r] + bias + rv[r]) * p.out_scale;
-                        o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ld_out] = act_fn(v, p.act_out);
+                        const float v = act_fn((acc[i][j][r] + bias + rv[r]) * p.out_scale, p.act_out);
+                        o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ld_out] = v;
+                        st_sum += v; st_sq += v * v;
                     }
+                }
+            }
+            // fused GroupNorm moments: this wave holds channel `co` of a whole 64-pixel run (lanes l and l^32
+            // share the channel); one writer per (run, channel) => deterministic, no atomics.
+            if (!partial && p.stats) {
+                st_sum += __shfl_xor(st_sum, 32);
+                st_sq += __shfl_xor(st_sq, 32);
+                if (half == 0) {
+                    float* sp = p.stats + ((size_t)((m0 >> 6) + wm) * p.Co + co) * 2;
+                    sp[0] = st_sum; sp[1] = st_sq;
                 }
             }
         }
@@ -377,25 +390,36 @@ static int conv_validate(const evc_conv_args* a) {
     return EVC_OK;
 }
 
+// Split-K choice.  Measured on MI355X (tools/conv_bench.hip): a workgroup alone on a CU is latency-bound
+// (~3.1 us per K-step against 1.4 us of MFMA time), two per CU take ~3.8 us per step pair, so small grids want
+// ~2.5 resident workgroups per CU (640 in all); a grid that already offers 384 tiles is left alone because the
+// slab write + combine traffic then costs more than the idle CUs.  At least 8 K-steps per split keep the
+// prologue / epilogue amortised.
 extern "C" int evc_conv_choose_splits(const evc_conv_args* a) {
     if (conv_validate(a) != EVC_OK) return EVC_EINVAL;
     if (a->splits > 0) return a->splits;
-    const int M = a->B * a->H * a->W;
+    const long long M = (long long)a->B * a->H * a->W;
     const int CoPad = evc_conv_co_pad(a->Co);
     const int BN = 64 * pick_tn(CoPad);
-    const long long tiles = (long long)((M + BM - 1) / BM) * (CoPad / BN);
+    const long long tiles = ((M + BM - 1) / BM) * (CoPad / BN);
     const int nsteps = a->KH * a->KW * ((a->C0 + a->C1) / KC);
-    // Fill the chip (256 CUs x 2 resident workgroups) when the tile grid alone cannot, but keep at
-    // least 8 K-steps per split so the prologue/epilogue stay amortised.
-    int splits = 1;
-    if (tiles < 384) {
-        splits = (int)((512 + tiles - 1) / tiles);
-        const int max_by_steps = nsteps / 8 > 0 ? nsteps / 8 : 1;
-        if (splits > max_by_steps) splits = max_by_steps;
-        if (splits > 32) splits = 32;
-        if (splits < 1) splits = 1;
-    }
-    return splits;
+    if (tiles >= 384) return 1;
+    long long splits = (640 + tiles / 2) / tiles;
+    const int max_by_steps = nsteps / 8 > 0 ? nsteps / 8 : 1;
+    if (splits > max_by_steps) splits = max_by_steps;
+    if (splits > 32) splits = 32;
+    if (splits < 1) splits = 1;
+    return (int)splits;
+}
+
+extern "C" int evc_conv_stats_splits(const evc_conv_args* a) {
+    if (conv_validate(a) != EVC_OK) return 0;
+    const int HW = a->H * a->W;
+    const long long M = (long long)a->B * HW;
+    const int CoPad = evc_conv_co_pad(a->Co);
+    if (HW % 64 != 0 || M % BM != 0 || a->Co != CoPad || a->Co % (64 * pick_tn(CoPad)) != 0) return 0;
+    if (evc_conv_choose_splits(a) != 1) return 0;
+    return HW / 64;
 }
 
 extern "C" long long evc_conv_workspace_bytes(const evc_conv_args* a) {
@@ -449,6 +473,8 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     k.splits = (k.nsteps + k.steps_per_split - 1) / k.steps_per_split;   // no empty splits
     k.ws = ws;
     if (k.splits > 1 && !ws) return EVC_EINVAL;
+    k.stats = a->stats_out;
+    if (k.stats && evc_conv_stats_splits(a) == 0) return EVC_EINVAL;
 
     const int tn = pick_tn(k.CoPad);
     const int BN = 64 * tn;

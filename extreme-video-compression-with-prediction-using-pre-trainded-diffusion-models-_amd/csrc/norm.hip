@@ -68,21 +68,29 @@ struct CoefArgs {
     float* coef_a; float* coef_s;
 };
 
-// grid (groups, B), block 64: one wave reduces a group's channels x splits in double.
-__global__ __launch_bounds__(64) void gn_coeffs_kernel(CoefArgs a) {
-    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+// grid (groups, B), block 256: the (split, channel) moments of one group are summed in double by the whole
+// block (fixed assignment + fixed tree => deterministic), then the group's channels get their coefficients.
+__global__ __launch_bounds__(256) void gn_coeffs_kernel(CoefArgs a) {
+    __shared__ double red[2][4];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int C = a.C0 + a.C1;
     const int cpg = C / a.groups;
     const int c_begin = g * cpg;
     double sm = 0.0, sq = 0.0;
-    for (int i = lane; i < cpg; i += 64) {
-        const int c = c_begin + i;
-        const float* part; int ns, cc, Cs;
-        if (c < a.C0) { part = a.part0; ns = a.nsplit0; cc = c; Cs = a.C0; }
-        else { part = a.part1; ns = a.nsplit1; cc = c - a.C0; Cs = a.C1; }
-        for (int s = 0; s < ns; ++s) {
-            const float* e = part + ((size_t)(b * ns + s) * Cs + cc) * 2;
-            sm += (double)e[0]; sq += (double)e[1];
+    // channels of this group that live in source 0 / source 1
+    const int n0 = max(0, min(c_begin + cpg, a.C0) - c_begin);
+    const int n1 = cpg - n0;
+    for (int i = tid; i < n0 * a.nsplit0; i += 256) {
+        const int s = i / n0, cc = c_begin + (i - s * n0);
+        const float2 e = *reinterpret_cast<const float2*>(a.part0 + ((size_t)(b * a.nsplit0 + s) * a.C0 + cc) * 2);
+        sm += (double)e.x; sq += (double)e.y;
+    }
+    if (n1 > 0) {
+        const int c1 = c_begin + n0 - a.C0;
+        for (int i = tid; i < n1 * a.nsplit1; i += 256) {
+            const int s = i / n1, cc = c1 + (i - s * n1);
+            const float2 e = *reinterpret_cast<const float2*>(a.part1 + ((size_t)(b * a.nsplit1 + s) * a.C1 + cc) * 2);
+            sm += (double)e.x; sq += (double)e.y;
         }
     }
 #pragma unroll
@@ -90,13 +98,17 @@ __global__ __launch_bounds__(64) void gn_coeffs_kernel(CoefArgs a) {
         sm += __shfl_xor(sm, off);
         sq += __shfl_xor(sq, off);
     }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = sm; red[1][tid >> 6] = sq; }
+    __syncthreads();
+    sm = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    sq = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     const double n = (double)cpg * (double)a.HW;
     const double mean = sm / n;
     double var = sq / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
     const float fmean = (float)mean;
-    for (int i = lane; i < cpg; i += 64) {
+    for (int i = tid; i < cpg; i += 256) {
         const int c = c_begin + i;
         float mul = 1.f, add = 0.f;
         if (a.mode == 1) { mul = a.gamma[c]; add = a.beta[c]; }
@@ -157,7 +169,7 @@ extern "C" int evc_gn_coeffs_f32(const float* part0, int nsplit0, int C0, const 
         return EVC_EINVAL;
     CoefArgs a{part0, nsplit0, C0, part1, nsplit1, C1, B, HW, groups, eps, mode, gamma, beta, ss, ss_ld, row,
                coef_a, coef_s};
-    hipLaunchKernelGGL(gn_coeffs_kernel, dim3(groups, B), dim3(64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(gn_coeffs_kernel, dim3(groups, B), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
 }
 

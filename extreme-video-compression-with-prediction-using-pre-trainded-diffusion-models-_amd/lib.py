@@ -35,7 +35,7 @@ class ConvArgs(ctypes.Structure):
                 ("out_scale", c_float), ("act_out", c_int),
                 ("out", c_void_p), ("ld_out", c_int),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("Co", c_int), ("KH", c_int), ("KW", c_int),
-                ("splits", c_int)]
+                ("splits", c_int), ("stats_out", c_void_p)]
 
 
 # name -> (restype, argtypes); exactly the symbols declared in include/evc_hip.h
@@ -60,6 +60,7 @@ HIP_SYMBOLS = {
     "evc_conv_pack_weights_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "evc_conv_choose_splits": (c_int, [POINTER(ConvArgs)]),
     "evc_conv_set_wave_layout": (c_int, [c_int]),
+    "evc_conv_stats_splits": (c_int, [POINTER(ConvArgs)]),
     "evc_conv_workspace_bytes": (c_longlong, [POINTER(ConvArgs)]),
     "evc_conv2d_nhwc_f32": (c_int, [POINTER(ConvArgs), c_void_p, c_void_p]),
     "evc_attention_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -312,9 +313,11 @@ def _src(s):
 
 
 def conv2d_nhwc(src0, w_packed, Co, KH, KW, bias=None, src1=None, coef=None, act_in=ACT_NONE, res=None,
-                out_scale=1.0, act_out=ACT_NONE, out=None, splits=0):
+                out_scale=1.0, act_out=ACT_NONE, out=None, splits=0, want_stats=False):
     """out = act_out((conv(act_in(cat[src0,src1]*a+s), w) + bias + res) * out_scale); tensors are NHWC.
-    ``src0`` / ``src1`` / ``out`` may be ``Cols`` channel slices of wider tensors."""
+    ``src0`` / ``src1`` / ``out`` may be ``Cols`` channel slices of wider tensors.
+    ``want_stats=True`` returns ``(out, stats)``: per-channel moments of ``out`` in ``chan_stats`` layout, produced
+    by the conv epilogue when the shape allows it, else by a separate ``evc_chan_stats_f32`` pass."""
     L = hip_lib()
     p0, C0, ld0, shp = _src(src0)
     p1, C1, ld1, shp1 = _src(src1)
@@ -328,7 +331,13 @@ def conv2d_nhwc(src0, w_packed, Co, KH, KW, bias=None, src1=None, coef=None, act
     ca, cs = coef if coef is not None else (None, None)
     a = ConvArgs(p0, p1, C0, C1, ld0, ld1, ptr(ca), ptr(cs), act_in, ptr(w_packed), ptr(bias), ptr(res),
                  0 if res is None else res.shape[-1], float(out_scale), act_out, po, ldo,
-                 B, H, W, Co, KH, KW, splits)
+                 B, H, W, Co, KH, KW, splits, None)
+    stats = None
+    if want_stats:
+        ns = L.evc_conv_stats_splits(ctypes.byref(a))
+        if ns > 0:
+            stats = torch.empty((B, ns, Co, 2), device=dev, dtype=torch.float32)
+            a.stats_out = ptr(stats)
     nbytes = L.evc_conv_workspace_bytes(ctypes.byref(a))
     if nbytes < 0:
         raise EvcKernelError(f"evc_conv_workspace_bytes rejected the arguments ({nbytes})")
@@ -343,7 +352,19 @@ def conv2d_nhwc(src0, w_packed, Co, KH, KW, bias=None, src1=None, coef=None, act
         CONV_PROFILE.append(dict(variant=conv_variant(Co), split=nbytes > 0, e0=e0, e1=e1,
                                  flops=2.0 * B * H * W * Co * KH * KW * (C0 + C1),
                                  shape=(B, H, W, C0 + C1, Co, KH)))
-    return out.t if isinstance(out, Cols) else out
+    result = out.t if isinstance(out, Cols) else out
+    if want_stats:
+        return result, (stats if stats is not None else chan_stats(result))
+    return result
+
+
+def conv_fused_stats_splits(B, H, W, Ci, Co, KH, KW, splits=0):
+    """HW/64 when ``conv2d_nhwc(..., want_stats=True)`` gets its moments from the conv epilogue for this shape,
+    0 when it falls back to a separate ``evc_chan_stats_f32`` pass (C query, no launch)."""
+    d = c_void_p(16)   # any non-null pointers: the query validates shapes only
+    a = ConvArgs(d, None, Ci, 0, 0, 0, None, None, ACT_NONE, d, None, None, 0, 1.0, ACT_NONE, d, Co, B, H, W, Co, KH,
+                 KW, splits, None)
+    return hip_lib(require_device=False).evc_conv_stats_splits(ctypes.byref(a))
 
 
 def attention(qkv, C, heads, out=None):

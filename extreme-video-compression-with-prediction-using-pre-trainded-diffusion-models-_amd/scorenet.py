@@ -89,9 +89,9 @@ class _Act:
     """An NHWC activation with lazily computed, cached per-channel moments."""
     __slots__ = ("t", "_stats")
 
-    def __init__(self, t):
+    def __init__(self, t, stats=None):
         self.t = t
-        self._stats = None
+        self._stats = stats
 
     def stats(self):
         if self._stats is None:
@@ -238,11 +238,12 @@ class ScoreNet:
                 k, up, down, pad = FIR_K, 1, 2, (1, 1)           # downsample_2d: pad (1, 1)
             hf = L.upfirdn2d_nhwc(x.t, k, up, down, pad, coef=coef0, act=L.ACT_SILU)
             xf = L.upfirdn2d_nhwc(x.t, k, up, down, pad)
-            h1 = _Act(L.conv2d_nhwc(hf, e["w0"], m["cout"], 3, 3, bias=e["b0"]))
+            h1 = _Act(*L.conv2d_nhwc(hf, e["w0"], m["cout"], 3, 3, bias=e["b0"], want_stats=True))
             xs_src, xs_skip = xf, None
         else:
-            h1 = _Act(L.conv2d_nhwc(x.t, e["w0"], m["cout"], 3, 3, bias=e["b0"],
-                                    src1=None if skip is None else skip.t, coef=coef0, act_in=L.ACT_SILU))
+            h1 = _Act(*L.conv2d_nhwc(x.t, e["w0"], m["cout"], 3, 3, bias=e["b0"],
+                                     src1=None if skip is None else skip.t, coef=coef0, act_in=L.ACT_SILU,
+                                     want_stats=True))
             xs_src, xs_skip = x.t, (None if skip is None else skip.t)
         H1, W1 = h1.t.shape[1], h1.t.shape[2]
         coef1 = self._adagn([h1.stats()], H1 * W1, m["cout"], e["ss1"], rows)
@@ -250,9 +251,8 @@ class ScoreNet:
             xs = L.conv2d_nhwc(xs_src, e["w2"], m["cout"], 1, 1, bias=e["b2"], src1=xs_skip)
         else:
             xs = xs_src
-        out = L.conv2d_nhwc(h1.t, e["w1"], m["cout"], 3, 3, bias=e["b1"], coef=coef1, act_in=L.ACT_SILU, res=xs,
-                            out_scale=INV_SQRT2)
-        return _Act(out)
+        return _Act(*L.conv2d_nhwc(h1.t, e["w1"], m["cout"], 3, 3, bias=e["b1"], coef=coef1, act_in=L.ACT_SILU,
+                                   res=xs, out_scale=INV_SQRT2, want_stats=True))
 
     def _attn(self, i, m, x):
         """AttnBlockpp.forward (models/better/layerspp.py:230-249)."""
@@ -263,8 +263,8 @@ class ScoreNet:
         coef = L.gn_coeffs([x.stats()], H * W, num_groups(C), 1e-6, mode=1, gamma=e["gamma"], beta=e["beta"])
         qkv = L.conv2d_nhwc(x.t, e["wqkv"], 3 * C, 1, 1, bias=e["bqkv"], coef=coef)
         o = L.attention(qkv.view(B, H * W, 3 * C), C, heads)
-        out = L.conv2d_nhwc(o.view(B, H, W, C), e["wo"], C, 1, 1, bias=e["bo"], res=x.t, out_scale=INV_SQRT2)
-        return _Act(out)
+        return _Act(*L.conv2d_nhwc(o.view(B, H, W, C), e["wo"], C, 1, 1, bias=e["bo"], res=x.t,
+                                   out_scale=INV_SQRT2, want_stats=True))
 
     @torch.no_grad()
     def forward_rows(self, x, rows, cond=None):
@@ -275,7 +275,7 @@ class ScoreNet:
         i = 2
         m = prog[i]
         xin = L.pack_nchw_to_nhwc(x, cond, self.w[i]["cin_pad"])
-        hs = [_Act(L.conv2d_nhwc(xin, self.w[i]["w"], m["cout"], 3, 3, bias=self.w[i]["b"]))]
+        hs = [_Act(*L.conv2d_nhwc(xin, self.w[i]["w"], m["cout"], 3, 3, bias=self.w[i]["b"], want_stats=True))]
         i += 1
         n_lvl = len(d.ch_mult)
         for lvl in range(n_lvl):
