@@ -319,18 +319,45 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
 }
 
 // out = act((sum_z ws[z] + bias + res) * scale): deterministic split-K combine.
-__global__ void conv_splitk_reduce_kernel(const float* ws, int splits, int M, int Co, const float* bias,
-                                          const float* res, int ld_res, float scale, int act, float* out,
-                                          int ld_out) {
+// Block = one 64-pixel run x 64 channels (thread: channel tid & 63, rows tid >> 6, +4, ...): 256-byte coalesced
+// rows, and -- when `stats` is given -- the per-channel {sum, sumsq} of the run in the layout of the fused
+// conv epilogue (one writer per (run, channel): deterministic, no atomics).
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M,
+                                                                 int Co, const float* __restrict__ bias,
+                                                                 const float* __restrict__ res, int ld_res,
+                                                                 float scale, int act, float* __restrict__ out,
+                                                                 int ld_out, float* __restrict__ stats) {
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int rg = threadIdx.x >> 6;
+    const int m_base = blockIdx.x * 64;
     const size_t total = (size_t)M * Co;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int m = (int)(i / Co), co = (int)(i - (size_t)m * Co);
-        float v = 0.f;
-        for (int z = 0; z < splits; ++z) v += ws[(size_t)z * total + i];
-        if (bias) v += bias[co];
-        if (res) v += res[(size_t)m * ld_res + co];
-        v *= scale;
-        out[(size_t)m * ld_out + co] = act_fn(v, act);
+    float s_sum = 0.f, s_sq = 0.f;
+    if (c < Co) {
+        const float b = bias ? bias[c] : 0.f;
+        for (int r = rg; r < 64; r += 4) {
+            const int m = m_base + r;
+            if (m >= M) break;
+            const size_t i = (size_t)m * Co + c;
+            float v = 0.f;
+            for (int z = 0; z < splits; ++z) v += ws[(size_t)z * total + i];
+            v += b;
+            if (res) v += res[(size_t)m * ld_res + c];
+            v = act_fn(v * scale, act);
+            out[(size_t)m * ld_out + c] = v;
+            s_sum += v; s_sq += v * v;
+        }
+    }
+    if (stats) {
+        red[0][rg][threadIdx.x & 63] = s_sum;
+        red[1][rg][threadIdx.x & 63] = s_sq;
+        __syncthreads();
+        if (rg == 0 && c < Co) {
+            const int l = threadIdx.x;
+            float* sp = stats + ((size_t)blockIdx.x * Co + c) * 2;
+            sp[0] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+            sp[1] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+        }
     }
 }
 
@@ -415,11 +442,12 @@ extern "C" int evc_conv_choose_splits(const evc_conv_args* a) {
 extern "C" int evc_conv_stats_splits(const evc_conv_args* a) {
     if (conv_validate(a) != EVC_OK) return 0;
     const int HW = a->H * a->W;
+    if (HW % 64 != 0) return 0;
+    if (evc_conv_choose_splits(a) > 1) return HW / 64;        // produced by the split-K combine kernel
     const long long M = (long long)a->B * HW;
     const int CoPad = evc_conv_co_pad(a->Co);
-    if (HW % 64 != 0 || M % BM != 0 || a->Co != CoPad || a->Co % (64 * pick_tn(CoPad)) != 0) return 0;
-    if (evc_conv_choose_splits(a) != 1) return 0;
-    return HW / 64;
+    if (M % BM != 0 || a->Co != CoPad || a->Co % (64 * pick_tn(CoPad)) != 0) return 0;
+    return HW / 64;                                            // produced by the conv epilogue (full tiles only)
 }
 
 extern "C" long long evc_conv_workspace_bytes(const evc_conv_args* a) {
@@ -473,8 +501,8 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     k.splits = (k.nsteps + k.steps_per_split - 1) / k.steps_per_split;   // no empty splits
     k.ws = ws;
     if (k.splits > 1 && !ws) return EVC_EINVAL;
-    k.stats = a->stats_out;
-    if (k.stats && evc_conv_stats_splits(a) == 0) return EVC_EINVAL;
+    k.stats = k.splits > 1 ? nullptr : a->stats_out;   // with split-K the combine kernel writes them
+    if (a->stats_out && evc_conv_stats_splits(a) == 0) return EVC_EINVAL;
 
     const int tn = pick_tn(k.CoPad);
     const int BN = 64 * tn;
@@ -486,10 +514,9 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     else launch_mode<1>(mode, grid, lds, st, k);
     if (hipGetLastError() != hipSuccess) return EVC_ELAUNCH;
     if (k.splits > 1) {
-        const size_t total = (size_t)k.M * k.Co;
-        int g = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(g), dim3(256), 0, st, ws, k.splits, k.M, k.Co, a->bias,
-                           a->res, a->ld_res, a->out_scale, a->act_out, a->out, a->ld_out);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((k.M + 63) / 64, (k.Co + 63) / 64), dim3(256), 0, st, ws,
+                           k.splits, k.M, k.Co, a->bias, a->res, a->ld_res, a->out_scale, a->act_out, a->out,
+                           a->ld_out, a->stats_out);
         if (hipGetLastError() != hipSuccess) return EVC_ELAUNCH;
     }
     return EVC_OK;

@@ -102,8 +102,8 @@ long long evc_conv_packed_floats(int Co, int Ci, int KH, int KW);
 /* w: [Co][Ci][KH][KW] (PyTorch Conv2d layout, device) -> packed (device). */
 int evc_conv_pack_weights_f32(const float* w, float* packed, int Co, int Ci, int KH, int KW, void* stream);
 int evc_conv_choose_splits(const evc_conv_args* a);
-/* H*W/64 when the fused epilogue moments are available for these arguments (no split-K, only full 128 x 64*TN
- * tiles, H*W % 64 == 0), else 0: the caller then runs evc_chan_stats_f32 on the output instead. */
+/* H*W/64 when the fused moments are available for these arguments (H*W % 64 == 0 and either split-K -- the combine
+ * kernel writes them -- or only full 128 x 64*TN tiles), else 0: the caller then runs evc_chan_stats_f32 instead. */
 int evc_conv_stats_splits(const evc_conv_args* a);
 /* Tuning hook: workgroup wave layout of the Co%192==0 kernel: 0 automatic, 1 = 4 waves (wave tile 64x96),
  * 2 = 8 waves (wave tile 32x96).  Results are identical; only speed differs. */

@@ -86,7 +86,8 @@ def test_conv_dispatch_queries_without_gpu():
     """Pure host logic of the C ABI: split-K choice and fused-moment eligibility (no launch)."""
     q = lib.conv_fused_stats_splits
     assert q(9, 128, 128, 192, 192, 3, 3) == 128 * 128 // 64      # full 128x192 tiles, no split-K
-    assert q(9, 8, 8, 768, 768, 3, 3) == 0                         # small grid -> split-K -> separate moments pass
+    assert q(9, 8, 8, 768, 768, 3, 3) == 1                         # small grid -> split-K -> moments from the combine kernel
+    assert q(9, 4, 4, 768, 768, 3, 3) == 0                         # HW not a multiple of the 64-pixel run
     assert q(2, 16, 16, 32, 96, 3, 3, splits=1) == 0               # Co not a whole number of column tiles
     assert q(1, 8, 24, 32, 192, 3, 3, splits=1) == 0               # M not a multiple of the 128-pixel tile
     assert q(1, 128, 128, 24, 192, 3, 3) == 0                      # invalid (channels % 16) -> never fused
