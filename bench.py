@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--clips", type=int, default=9, help="clips per GPU per step (configs[1]: start 0 end 8)")
     ap.add_argument("--subsample", type=int, default=100)
     ap.add_argument("--sampler", default="DDPM", choices=["DDPM", "DDIM", "FPNDM"])
+    ap.add_argument("--groups", type=int, default=2,
+                    help="concurrent clip groups per GPU during generation (one HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -122,7 +124,7 @@ def main():
     sd_e = D.broadcast_state_dict(sd_e, src=0, device=device, world=world)
     net = ScoreNet(cfg, sd_d, device=device)
     elic = ElicModel(sd_e, device=device)
-    dec = ClipDecoder(net, elic, cfg, S.get_sampler(a.sampler))
+    dec = ClipDecoder(net, elic, cfg, S.get_sampler(a.sampler), groups=a.groups)
 
     # inputs: this rank's clips; key frames 0,1 are ELIC-encoded once (sender side, untimed)
     clips = torch.from_numpy(synthetic.make_clips(a.clips, seed=100 + rank).astype(np.float32) / 255.0)
@@ -158,7 +160,8 @@ def main():
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"configs[1]: {a.clips} clips/GPU x 30 frames 128x128, q3, 2 ELIC key frames + "
                                   f"6 chunks x {fwd_per_chunk} forwards ({a.sampler}-{a.subsample}), B={a.clips} per launch",
-                      "parallelism": f"clip-sharded dp{world}, no data-path collective",
+                      "parallelism": f"clip-sharded dp{world}, no data-path collective; {a.groups} concurrent clip "
+                                     f"group(s) per GPU",
                       "weights": "seeded random, reference architecture (262.1M + ELIC)"},
            "whole_path_tflops_per_gpu": round(flop_per_step_gpu * a.steps / elapsed / 1e12, 2)}
     if rank == 0:

@@ -34,7 +34,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+#ifndef EVC_CONV_ABLATE
+#define EVC_CONV_ABLATE 0      // DIAGNOSTIC ONLY (wrong results): bit 0 = skip the weight DMA, bit 1 = skip the activation path
+#endif
+#ifndef EVC_CONV_PLAIN_DMA
+#define EVC_CONV_PLAIN_DMA 0   // 1: in plain mode the activation tile also goes global -> LDS by DMA (out-of-image lanes
+                               // read a zero page). Measured equal to register staging on MI355X; kept as an option.
+#endif
+
 namespace {
+
+__device__ float g_zero_page[64];   // source of out-of-image taps for the DMA path (zero-initialised)
 
 constexpr int BM = 128;      // pixels per workgroup tile
 constexpr int KC = 16;       // channels per K step (one 64-byte LDS row)
@@ -91,6 +101,7 @@ template <int TN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     constexpr int BN = 64 * TN;
     constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
+    constexpr bool DMA_A = EVC_CONV_PLAIN_DMA && MODE == MODE_PLAIN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As = smem;                    // [2][BM][16]
     float* const Ws = smem + 2 * BM * KC;      // [2][BN][16]
@@ -135,6 +146,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
             }
         okmask[i] = mask;
         a_lds[i] = row * KC + 4 * (k4 ^ ((row >> 2) & 3));        // swizzled float offset inside an A buffer
+        if (DMA_A) {   // DMA lands lane-linear: this lane fills physical chunk k4, i.e. logical chunk k4 ^ f(row)
+            const unsigned kq = (unsigned)(k4 ^ ((row >> 2) & 3));
+            off0[i] = ((unsigned)mm * (unsigned)p.ld0 + 4u * kq) * 4u;
+            off1[i] = ((unsigned)mm * (unsigned)p.ld1 + 4u * kq) * 4u;
+        }
     }
 
     // fragment read offsets (floats): chunk c = 2*kk + half sits at position c ^ ((row >> 2) & 3); tile and
@@ -175,16 +191,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         // uniform byte delta of this (tap, chunk) relative to the output pixel's channel 0
         const int delta = (((c_ty - padH) * p.W + (c_tx - padW)) * ld + (first ? c : c - p.C0)) * 4;
         const unsigned safe = (unsigned)((first ? c : c - p.C0) + 4 * k4) * 4u;   // pixel 0: always legal
+        if (DMA_A) {
+            float* al = As + buf * BM * KC;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            aok[i] = (okmask[i] >> tap) & 1u;
-            const unsigned o = aok[i] ? (first ? off0[i] : off1[i]) + (unsigned)delta : safe;
-            areg[i] = *reinterpret_cast<const float4*>(src + o);
+            for (int i = 0; i < 2; ++i) {
+                const bool ok = (okmask[i] >> tap) & 1u;
+                const char* g = ok ? src + ((first ? off0[i] : off1[i]) + (unsigned)delta)
+                                   : reinterpret_cast<const char*>(g_zero_page) + 16 * k4;
+                __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(al + (wave * 16 + 64 * i) * KC), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                aok[i] = (okmask[i] >> tap) & 1u;
+                const unsigned o = aok[i] ? (first ? off0[i] : off1[i]) + (unsigned)delta : safe;
+                areg[i] = *reinterpret_cast<const float4*>(src + o);
+            }
         }
         const float* wt = p.w + ((size_t)(tap * p.nchunk + c_chunk) * p.CoPad + n0) * KC;
         float* wl = Ws + buf * BN * KC;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)     // one wave instruction moves 16 rows (1 KiB); 4 waves x TN rounds
+        for (int j = 0; j < ((EVC_CONV_ABLATE & 1) ? 0 : TN); ++j)     // one wave instruction moves 16 rows (1 KiB); 4 waves x TN rounds
             __builtin_amdgcn_global_load_lds((glb_void*)(wt + (size_t)(tid + 256 * j) * 4),
                                              (lds_void*)(wl + (wave * 16 + 64 * j) * KC), 16, 0, 0);
     };
@@ -194,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         if (c_ty == p.KH) { c_ty = 0; ++c_chunk; }
     };
     auto store_a = [&](int buf) {
+        if (DMA_A) return;
         float* A = As + buf * BM * KC;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -225,6 +253,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
             if (HAS_COEF && c_chunk != prev_chunk) load_coefs();      // wave-uniform, once per KH*KW steps
         }
         issue_loads(buf ^ 1);
+#if EVC_CONV_ABLATE & 2
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(areg[i].x), "v"(areg[i].y), "v"(areg[i].z), "v"(areg[i].w));
+#endif
 
         const float* Ab = As + buf * BM * KC + a_rd;
         const float* Wb = Ws + buf * BN * KC + w_rd;
@@ -239,7 +271,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         for (int j = 0; j < TN; ++j) b1[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * KC + rd1);
         mfma_group<TN>(acc, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
+#if !(EVC_CONV_ABLATE & 2)
         store_a(buf ^ 1);            // producer work for the next step sits among the second half of the MFMAs
+#endif
         mfma_group<TN>(acc, a1, b1);
         __syncthreads();             // also drains the W DMA (vmcnt) before anyone reads the new buffers
     }

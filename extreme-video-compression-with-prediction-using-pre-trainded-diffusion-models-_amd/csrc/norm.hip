@@ -129,7 +129,8 @@ __device__ __forceinline__ float act_fn(float v, int act) {
 }
 
 __global__ void affine_act_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ ca,
-                                  const float* __restrict__ cs, int act, int HW, int C, size_t total4) {
+                                  const float* __restrict__ cs, int act, int HW, int C, int ld_coef, int ld_out,
+                                  size_t total4) {
     const int C4 = C >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
@@ -137,12 +138,12 @@ __global__ void affine_act_kernel(const float* __restrict__ x, float* __restrict
         const int b = (int)(pix / HW);
         float4 v = reinterpret_cast<const float4*>(x)[i];
         if (ca) {
-            const float4 a = *reinterpret_cast<const float4*>(ca + (size_t)b * C + 4 * c4);
-            const float4 s = *reinterpret_cast<const float4*>(cs + (size_t)b * C + 4 * c4);
+            const float4 a = *reinterpret_cast<const float4*>(ca + (size_t)b * ld_coef + 4 * c4);
+            const float4 s = *reinterpret_cast<const float4*>(cs + (size_t)b * ld_coef + 4 * c4);
             v.x = v.x * a.x + s.x; v.y = v.y * a.y + s.y; v.z = v.z * a.z + s.z; v.w = v.w * a.w + s.w;
         }
         v.x = act_fn(v.x, act); v.y = act_fn(v.y, act); v.z = act_fn(v.z, act); v.w = act_fn(v.w, act);
-        reinterpret_cast<float4*>(y)[i] = v;
+        *reinterpret_cast<float4*>(y + pix * (size_t)ld_out + 4 * c4) = v;
     }
 }
 
@@ -174,12 +175,15 @@ extern "C" int evc_gn_coeffs_f32(const float* part0, int nsplit0, int C0, const 
 }
 
 extern "C" int evc_affine_act_nhwc_f32(const float* x, float* y, const float* coef_a, const float* coef_s, int act,
-                                       int B, int HW, int C, void* stream) {
+                                       int B, int HW, int C, int ld_coef, int ld_out, void* stream) {
     if (!x || !y || B <= 0 || HW <= 0 || C <= 0 || (C & 3) || ((coef_a == nullptr) != (coef_s == nullptr)))
         return EVC_EINVAL;
+    if (ld_coef == 0) ld_coef = C;
+    if (ld_out == 0) ld_out = C;
+    if (ld_coef < C || ld_out < C || (ld_coef & 3) || (ld_out & 3)) return EVC_EINVAL;
     const size_t total4 = (size_t)B * HW * (C >> 2);
     int grid = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
     hipLaunchKernelGGL(affine_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, coef_a, coef_s, act,
-                       HW, C, total4);
+                       HW, C, ld_coef, ld_out, total4);
     return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
 }

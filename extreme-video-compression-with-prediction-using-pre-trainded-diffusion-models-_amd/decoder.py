@@ -25,31 +25,77 @@ def all_generated_mask(frames=30, key=2, chunk=5):
 
 
 class ClipDecoder:
-    def __init__(self, scorenet, elic_model, config, sampler):
+    def __init__(self, scorenet, elic_model, config, sampler, groups=1):
         self.net, self.elic, self.config, self.sampler = scorenet, elic_model, config, sampler
         self.device = scorenet.device
+        self.groups = groups          # concurrent clip groups (HIP streams) during generation
+        self._stream_pool = []
 
     @torch.no_grad()
-    def generate(self, cond_frames, noise_fn=None, generator=None):
+    def generate(self, cond_frames, noise_fn=None, generator=None, groups=None):
         """cond_frames: (B, 2, 3, H, W) in [0, 1] on the device -> (B, 5, 3, H, W) in [0, 1].
-        = SenderCity.generate_frame (city_sender.py:326-351) without the per-chunk checkpoint reload."""
+        = SenderCity.generate_frame (city_sender.py:326-351) without the per-chunk checkpoint reload.
+
+        ``groups`` > 1 splits the batch into that many clip groups that are sampled concurrently, each on its
+        own HIP stream (clips are independent): idle CUs during one group's small kernels / partial tile rounds
+        run another group's convolutions.  Per-clip results do not depend on the grouping when noise is injected
+        (``noise_fn`` is then called per group with the group's slice bounds)."""
+        from . import sampler as S
         cfg = self.config
         B, _, C, H, W = cond_frames.shape
+        groups = self.groups if groups is None else groups
+        groups = max(1, min(int(groups), B))
         cond = cond_frames.reshape(B, -1, H, W).contiguous()
         if cfg.data.rescaled:
             cond = L.scale_clamp(cond, 2.0, -1.0)                          # data_transform: 2x - 1
-        shape = (B, cfg.data.channels * cfg.data.num_frames, H, W)
-        x_T = noise_fn("init", shape) if noise_fn is not None else \
-            torch.randn(shape, device=self.device, dtype=torch.float32, generator=generator)
-        step_noise = None if noise_fn is None else (lambda i, x: noise_fn(i, tuple(x.shape)))
-        out = self.sampler(x_T.to(self.device), self.net, cond=cond, final_only=True,
-                           denoise=cfg.sampling.denoise, subsample_steps=getattr(cfg.sampling, "subsample", None),
-                           clip_before=getattr(cfg.sampling, "clip_before", True), noise_fn=step_noise,
-                           generator=generator)
-        pred = out[-1].contiguous()
+        ch = cfg.data.channels * cfg.data.num_frames
+        kw = dict(final_only=True, denoise=cfg.sampling.denoise, subsample_steps=getattr(cfg.sampling, "subsample", None),
+                  clip_before=getattr(cfg.sampling, "clip_before", True))
+        step_gen = S.get_step_generator(self.sampler)
+
+        def draw(tag, lo, hi, gen_):
+            shp = (hi - lo, ch, H, W)
+            if noise_fn is not None:
+                return noise_fn(tag, (B, ch, H, W))[lo:hi].to(self.device).contiguous()
+            return torch.randn(shp, device=self.device, dtype=torch.float32, generator=gen_)
+
+        if groups == 1 or step_gen is None:
+            x_T = draw("init", 0, B, generator)
+            step_noise = None if noise_fn is None else (lambda i, x: draw(i, 0, B, None))
+            out = self.sampler(x_T, self.net, cond=cond, noise_fn=step_noise, generator=generator, **kw)
+            pred = out[-1].contiguous()
+        else:
+            bounds = [(g * B // groups, (g + 1) * B // groups) for g in range(groups)]
+            main = torch.cuda.current_stream()
+            streams = self._streams(groups)
+            if hasattr(self.net, "prepare_labels"):   # table rows are shared state: build them once, up front
+                n = kw["subsample_steps"] or len(self.net.betas)
+                skip = max(1, len(self.net.betas) // n)
+                self.net.prepare_labels([float(v) for v in range(0, len(self.net.betas), skip)] + [float(n - 1)])
+            gens = []
+            for (lo, hi), st in zip(bounds, streams):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    gen_g = None
+                    if noise_fn is None:
+                        gen_g = torch.Generator(device=self.device)
+                        gen_g.manual_seed(int(torch.randint(0, 2 ** 31 - 1, (1,), generator=generator, device=self.device))
+                                          if generator is not None else torch.seed() % (2 ** 31))
+                    x_T = draw("init", lo, hi, gen_g)
+                    sn = None if noise_fn is None else (lambda i, x, lo=lo, hi=hi: draw(i, lo, hi, None))
+                    gens.append(step_gen(x_T, self.net, cond=cond[lo:hi].contiguous(), noise_fn=sn, generator=gen_g, **kw))
+            outs = S.run_interleaved(gens, streams)
+            for st in streams:
+                main.wait_stream(st)
+            pred = torch.cat([o[-1] for o in outs], dim=0).contiguous()
         pred = L.scale_clamp(pred, 0.5, 0.5, (0.0, 1.0)) if cfg.data.rescaled else \
             L.scale_clamp(pred, 1.0, 0.0, (0.0, 1.0))                         # inverse_data_transform
         return pred.reshape(B, cfg.data.num_frames, C, H, W)
+
+    def _streams(self, n):
+        while len(self._stream_pool) < n:
+            self._stream_pool.append(torch.cuda.Stream(device=self.device))
+        return self._stream_pool[:n]
 
     @torch.no_grad()
     def decode(self, d, key_strings, shape, frames=30, noise_fn=None, generator=None):

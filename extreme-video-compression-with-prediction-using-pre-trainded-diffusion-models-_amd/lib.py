@@ -53,8 +53,8 @@ HIP_SYMBOLS = {
     "evc_gn_coeffs_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                   c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
-    "evc_affine_act_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                        c_void_p]),
+    "evc_affine_act_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, c_void_p]),
     "evc_conv_co_pad": (c_int, [c_int]),
     "evc_conv_packed_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
     "evc_conv_pack_weights_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -248,15 +248,22 @@ def gn_coeffs(parts, HW, groups, eps, mode=0, gamma=None, beta=None, ss=None, ro
     return ca, cs
 
 
-def affine_act(x, coef, act, out=None):
+def affine_act(x, coef, act, out=None, coef_col=0):
+    """y = act(x * a + s).  ``out`` may be a ``Cols`` slice of a wider buffer; ``coef_col`` selects the channel
+    offset inside wider (B, Ctot) coefficient tensors (both let a concat be activated piecewise)."""
     L = hip_lib()
     B, H, W, C = x.shape
     if out is None:
         out = torch.empty_like(x)
+    po, Cout, ldo, _ = _src(out)
+    assert Cout == C
     ca, cs = coef if coef is not None else (None, None)
-    _check(L.evc_affine_act_nhwc_f32(fptr(x), fptr(out), fptr(ca), fptr(cs), act, B, H * W, C, stream_ptr()),
+    ldc = 0 if ca is None else ca.shape[-1]
+    pa = None if ca is None else c_void_p(ca.data_ptr() + 4 * coef_col)
+    ps = None if cs is None else c_void_p(cs.data_ptr() + 4 * coef_col)
+    _check(L.evc_affine_act_nhwc_f32(fptr(x), po, pa, ps, act, B, H * W, C, ldc, ldo, stream_ptr()),
            "evc_affine_act_nhwc_f32")
-    return out
+    return out.t if isinstance(out, Cols) else out
 
 
 def conv_pack_weights(w):

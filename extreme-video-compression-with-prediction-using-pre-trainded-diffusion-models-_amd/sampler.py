@@ -47,10 +47,42 @@ def _prepare(net, labels):
         net.prepare_labels(labels)
 
 
+def _run(gen):
+    """Exhaust a step generator and return its value."""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as e:
+        return e.value
+
+
+def run_interleaved(gens, streams):
+    """Drive several independent sampler generators in lockstep, each on its own HIP stream: one network
+    evaluation of every generator is enqueued per round, so the small latency-bound kernels and partial tile
+    rounds of one group overlap the large convolutions of another.  Returns the generators' results in order.
+    The caller's current stream must have been waited on by ``streams`` (inputs) and must wait on them after."""
+    results = [None] * len(gens)
+    live = list(range(len(gens)))
+    while live:
+        for i in list(live):
+            with torch.cuda.stream(streams[i]):
+                try:
+                    next(gens[i])
+                except StopIteration as e:
+                    results[i] = e.value
+                    live.remove(i)
+    return results
+
+
 @torch.no_grad()
-def ddpm_sampler(x_mod, scorenet, cond=None, just_beta=False, final_only=False, denoise=True,
-                 subsample_steps=None, same_noise=False, noise_val=None, frac_steps=None, verbose=False,
-                 log=False, clip_before=True, t_min=-1, gamma=False, noise_fn=None, generator=None, **kwargs):
+def ddpm_sampler(*args, **kwargs):
+    return _run(ddpm_steps(*args, **kwargs))
+
+
+def ddpm_steps(x_mod, scorenet, cond=None, just_beta=False, final_only=False, denoise=True,
+               subsample_steps=None, same_noise=False, noise_val=None, frac_steps=None, verbose=False,
+               log=False, clip_before=True, t_min=-1, gamma=False, noise_fn=None, generator=None, **kwargs):
+    """Generator form of ``ddpm_sampler``: yields after every network evaluation + update."""
     if gamma or frac_steps is not None or t_min > 0:
         raise NotImplementedError("gamma / frac_steps / t_min>0 are unreachable from the reference CLI")
     net = _net(scorenet)
@@ -80,17 +112,24 @@ def ddpm_sampler(x_mod, scorenet, cond=None, just_beta=False, final_only=False, 
         L.ddpm_step(x, e, noise, k1, k2, c1, c2, sigma, clip_before)
         if not final_only:
             images.append(x.to("cpu"))
+        yield
     if denoise:
         e = _eps(net, x, L_ - 1, cond)   # label is the COUNT index L-1 (models/__init__.py:333-335)
         x = L.axpy(x, e, -float((1 - alphas[-1]).sqrt()))
         if not final_only:
             images.append(x.to("cpu"))
+        yield
     return x.unsqueeze(0) if final_only else torch.stack(images)
 
 
 @torch.no_grad()
-def ddim_sampler(x_mod, scorenet, cond=None, final_only=False, denoise=True, subsample_steps=None, verbose=False,
-                 log=True, clip_before=True, t_min=-1, gamma=False, **kwargs):
+def ddim_sampler(*args, **kwargs):
+    return _run(ddim_steps(*args, **kwargs))
+
+
+def ddim_steps(x_mod, scorenet, cond=None, final_only=False, denoise=True, subsample_steps=None, verbose=False,
+               log=True, clip_before=True, t_min=-1, gamma=False, **kwargs):
+    """Generator form of ``ddim_sampler``."""
     if gamma or t_min > 0:
         raise NotImplementedError("gamma / t_min>0 are unreachable from the reference CLI")
     net = _net(scorenet)
@@ -106,11 +145,13 @@ def ddim_sampler(x_mod, scorenet, cond=None, final_only=False, denoise=True, sub
                     float((1 - c_alpha_prev).sqrt()), clip_before)
         if not final_only:
             images.append(x.to("cpu"))
+        yield
     if denoise:
         e = _eps(net, x, L_ - 1, cond)
         x = L.axpy(x, e, -float((1 - alphas[-1]).sqrt()))
         if not final_only:
             images.append(x.to("cpu"))
+        yield
     return x.unsqueeze(0) if final_only else torch.stack(images)
 
 
@@ -125,9 +166,13 @@ def _transfer(x, t, t_next, e, alphas_cump, clip_before):
 
 
 @torch.no_grad()
-def FPNDM_sampler(x_mod, scorenet, cond=None, final_only=False, denoise=True, subsample_steps=None, verbose=False,
-                  log=True, clip_before=True, t_min=-1, gamma=False, **kwargs):
-    """FPNDM_sampler + pndm.gen_order_4 / runge_kutta (models/__init__.py:39-100, models/pndm.py:3-52):
+def FPNDM_sampler(*args, **kwargs):
+    return _run(fpndm_steps(*args, **kwargs))
+
+
+def fpndm_steps(x_mod, scorenet, cond=None, final_only=False, denoise=True, subsample_steps=None, verbose=False,
+                log=True, clip_before=True, t_min=-1, gamma=False, **kwargs):
+    """Generator form of ``FPNDM_sampler`` (yields once per outer iteration).  FPNDM_sampler + pndm.gen_order_4 / runge_kutta (models/__init__.py:39-100, models/pndm.py:3-52):
     3 Runge-Kutta warm-up iterations (4 evaluations each) then 4-term Adams-Bashforth; no denoise call."""
     net = _net(scorenet)
     alphas_old = net.alphas.cpu().flip(0)
@@ -159,7 +204,16 @@ def FPNDM_sampler(x_mod, scorenet, cond=None, final_only=False, denoise=True, su
         x = _transfer(x, t, tn, e, alphas_old, clip_before)
         if not final_only:
             images.append(x.to("cpu"))
+        yield
     return x.unsqueeze(0) if final_only else torch.stack(images)
+
+
+STEP_GENERATORS = {}
+
+
+def get_step_generator(sampler_fn):
+    """The generator form of a sampler returned by ``get_sampler`` (None for foreign callables)."""
+    return {ddpm_sampler: ddpm_steps, ddim_sampler: ddim_steps, FPNDM_sampler: fpndm_steps}.get(sampler_fn)
 
 
 def get_sampler(version):

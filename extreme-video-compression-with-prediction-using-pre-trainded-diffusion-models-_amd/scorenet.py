@@ -106,8 +106,14 @@ def _pad16(c):
 class ScoreNet:
     """HIP implementation of ``UNetMore_DDPM`` (eval mode, dropout 0, spade/cond_emb/noise_in_cond off)."""
 
-    def __init__(self, config, state_dict, device="cuda", prefix=""):
+    def __init__(self, config, state_dict, device="cuda", prefix="", preactivate=False):
         L.hip_lib()   # fail loudly before touching anything else
+        # preactivate=False: AdaGN + SiLU is fused into the 3x3 convolutions' operand load (evaluated once per
+        # filter tap, costs MFMA issue slots); True: applied once per tensor by evc_affine_act_nhwc_f32 and the
+        # convolutions read the activated tensor as is (one extra HBM round trip per tensor).  Same values either
+        # way; on MI355X at B=9 the two tie (38.6 vs 38.4 ms per forward, interleaved A/B), so the fused form
+        # with less memory traffic is the default.
+        self.preactivate = preactivate
         self.config = config
         self.device = torch.device(device)
         self.d = dims_from_config(config)
@@ -240,6 +246,15 @@ class ScoreNet:
             xf = L.upfirdn2d_nhwc(x.t, k, up, down, pad)
             h1 = _Act(*L.conv2d_nhwc(hf, e["w0"], m["cout"], 3, 3, bias=e["b0"], want_stats=True))
             xs_src, xs_skip = xf, None
+        elif self.preactivate:
+            cin = m["cin"]
+            act = torch.empty((B, H, W, cin), device=self.device, dtype=torch.float32)
+            c0 = x.t.shape[3]
+            L.affine_act(x.t, coef0, L.ACT_SILU, out=L.Cols(act, 0, c0))
+            if skip is not None:
+                L.affine_act(skip.t, coef0, L.ACT_SILU, out=L.Cols(act, c0, cin - c0), coef_col=c0)
+            h1 = _Act(*L.conv2d_nhwc(act, e["w0"], m["cout"], 3, 3, bias=e["b0"], want_stats=True))
+            xs_src, xs_skip = x.t, (None if skip is None else skip.t)
         else:
             h1 = _Act(*L.conv2d_nhwc(x.t, e["w0"], m["cout"], 3, 3, bias=e["b0"],
                                      src1=None if skip is None else skip.t, coef=coef0, act_in=L.ACT_SILU,
@@ -251,6 +266,10 @@ class ScoreNet:
             xs = L.conv2d_nhwc(xs_src, e["w2"], m["cout"], 1, 1, bias=e["b2"], src1=xs_skip)
         else:
             xs = xs_src
+        if self.preactivate:
+            h1a = L.affine_act(h1.t, coef1, L.ACT_SILU)
+            return _Act(*L.conv2d_nhwc(h1a, e["w1"], m["cout"], 3, 3, bias=e["b1"], res=xs, out_scale=INV_SQRT2,
+                                       want_stats=True))
         return _Act(*L.conv2d_nhwc(h1.t, e["w1"], m["cout"], 3, 3, bias=e["b1"], coef=coef1, act_in=L.ACT_SILU,
                                    res=xs, out_scale=INV_SQRT2, want_stats=True))
 

@@ -69,9 +69,12 @@ int evc_gn_coeffs_f32(const float* part0, int nsplit0, int C0, const float* part
                       int HW, int groups, float eps, int mode, const float* gamma, const float* beta,
                       const float* ss, int ss_ld, const int* row, float* coef_a, float* coef_s, void* stream);
 
-/* y = act(x*coef_a[b][c] + coef_s[b][c]) elementwise on NHWC (stand-alone form of the fused load). */
+/* y = act(x*coef_a[b][c] + coef_s[b][c]) elementwise on NHWC: the stand-alone form of the fused load.  One pass per
+ * tensor instead of once per filter tap inside the convolution (SiLU costs MFMA issue slots there; HBM is cheap).
+ * `coef_*` rows have stride ld_coef (0 = C) so a slice of a concat's coefficients can be used; `y` rows have stride
+ * ld_out (0 = C) so two tensors can be activated side by side into one buffer (materialised concat). */
 int evc_affine_act_nhwc_f32(const float* x, float* y, const float* coef_a, const float* coef_s, int act, int B,
-                            int HW, int C, void* stream);
+                            int HW, int C, int ld_coef, int ld_out, void* stream);
 
 /* ---- convolution as implicit GEMM on the f32 matrix cores ----------------------------------
  * Stride-1 "same" convolution (odd KH x KW, zero padding) over the virtual concat [src0 | src1] of

@@ -109,3 +109,7 @@ def test_hip_net_against_cpu_oracle_same_weights():
     ref = O.forward(p, d, x, torch.tensor([120, 120, 120]), cond=cond)
     out = net(x.cuda(), torch.tensor([120, 120, 120]), cond=cond.cuda())
     assert rel(out, ref.numpy()) < 1e-4
+    # both placements of AdaGN + SiLU (one pre-activation pass per tensor / fused into the conv operand load)
+    net.preactivate = not net.preactivate
+    out2 = net(x.cuda(), torch.tensor([120, 120, 120]), cond=cond.cuda())
+    assert rel(out2, ref.numpy()) < 1e-4 and rel(out2, out.cpu().numpy()) < 2e-5

@@ -52,9 +52,13 @@ def forward_probe(Bs):
     print(f"weights built+packed in {time.time() - t0:.1f}s", flush=True)
     for B in Bs:
         x, c = torch.randn(B, 15, 128, 128, device="cuda"), torch.randn(B, 6, 128, 128, device="cuda")
-        net.forward_label(x, 500, c)
-        t = timeit(lambda: net.forward_label(x, 500, c), iters=3, warm=1)
-        print(f"forward B={B}: {t:.1f} ms  -> {345.2 * B / t:.1f} TFLOP/s, {t / B:.1f} ms/sample", flush=True)
+        for rep in range(2):
+            for pre in (False, True):     # interleaved A/B in one process on one device
+                net.preactivate = pre
+                net.forward_label(x, 500, c)
+                t = timeit(lambda: net.forward_label(x, 500, c), iters=3, warm=1)
+                print(f"forward B={B} preactivate={pre}: {t:.1f} ms  -> {345.2 * B / t:.1f} TFLOP/s, "
+                      f"{t / B:.1f} ms/sample", flush=True)
 
 
 if __name__ == "__main__":
