@@ -292,7 +292,11 @@ def conv_variant(Co):
 
 
 def _workspace(nbytes, device):
-    """Grow-only split-K workspace per device (stream-ordered reuse on the current stream)."""
+    """Split-K workspace.  Eager launches: one grow-only buffer per (device, stream), reused stream-ordered.
+    Inside a HIP-graph capture every graph must own its buffer (all captures share one capture stream, and
+    graphs replayed concurrently on different streams would otherwise race on it): allocate from the graph pool."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(((nbytes + 3) // 4,), device=device, dtype=torch.float32)
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     cur = _ws_cache.get(key)
     if cur is None or cur.numel() * 4 < nbytes:

@@ -85,7 +85,8 @@ def test_generation_is_invariant_to_concurrent_clip_grouping():
 
     def noise_fn(tag, shp):      # pure function of the tag, so every group slices the same tensor
         return rnd(hash(str(tag)) % 1000 + 7, *shp)
-    for name in ("DDPM", "DDIM"):
+    for name, graphs in (("DDPM", False), ("DDIM", False), ("DDPM", True)):
+        net.use_graphs = graphs
         dec = ClipDecoder(net, None, cfg, S.get_sampler(name))
         one = dec.generate(cond, noise_fn=noise_fn, groups=1)
         three = dec.generate(cond, noise_fn=noise_fn, groups=3)

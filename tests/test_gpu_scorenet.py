@@ -113,3 +113,21 @@ def test_hip_net_against_cpu_oracle_same_weights():
     net.preactivate = not net.preactivate
     out2 = net(x.cuda(), torch.tensor([120, 120, 120]), cond=cond.cuda())
     assert rel(out2, ref.numpy()) < 1e-4 and rel(out2, out.cpu().numpy()) < 2e-5
+
+
+def test_graph_replay_equals_eager_launches():
+    """The captured HIP graph replays exactly the eager launch sequence (bitwise), across labels and repeats."""
+    net, d, p = build(32, 32, 32, 55)
+    x, cond = rnd(56, 2, 15, 32, 32).cuda(), rnd(57, 2, 6, 32, 32).cuda()
+    net.use_graphs = False
+    eager = [net.forward_label(x, lab, cond).clone() for lab in (0, 500, 990)]
+    net.use_graphs = True
+    for rep in range(2):
+        for lab, ref in zip((0, 500, 990), eager):
+            assert torch.equal(net.forward_label(x, lab, cond), ref)
+    x2 = rnd(58, 2, 15, 32, 32).cuda()      # new inputs through the same graph
+    net.use_graphs = False
+    ref = net.forward_label(x2, 500, cond).clone()
+    net.use_graphs = True
+    assert torch.equal(net.forward_label(x2, 500, cond), ref)
+    assert len(net._graphs) == 1      # one (stream, shape) -> one graph, reused for every label and input

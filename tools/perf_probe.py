@@ -53,12 +53,16 @@ def forward_probe(Bs):
     for B in Bs:
         x, c = torch.randn(B, 15, 128, 128, device="cuda"), torch.randn(B, 6, 128, 128, device="cuda")
         for rep in range(2):
-            for pre in (False, True):     # interleaved A/B in one process on one device
-                net.preactivate = pre
+            for graphs in (False, True):     # interleaved A/B in one process on one device
+                net.use_graphs = graphs
                 net.forward_label(x, 500, c)
+                torch.cuda.synchronize()
+                h0 = time.perf_counter()
+                net.forward_label(x, 500, c)
+                host_ms = (time.perf_counter() - h0) * 1e3      # host time to enqueue one forward
                 t = timeit(lambda: net.forward_label(x, 500, c), iters=3, warm=1)
-                print(f"forward B={B} preactivate={pre}: {t:.1f} ms  -> {345.2 * B / t:.1f} TFLOP/s, "
-                      f"{t / B:.1f} ms/sample", flush=True)
+                print(f"forward B={B} graphs={graphs}: {t:.1f} ms  -> {345.2 * B / t:.1f} TFLOP/s, "
+                      f"{t / B:.1f} ms/sample, host enqueue {host_ms:.1f} ms", flush=True)
 
 
 if __name__ == "__main__":
