@@ -72,8 +72,15 @@ def roofline_leg(net, clips, device):
     d = per[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     total_conv_ms = sum(v["ms"] for v in per.values()) / 3
+    traffic = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes (same kernel, same batch)
+    try:
+        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_conv_pmc.json")))
+        if clips == 9 and pmc.get("kernel") == f"conv_igemm_kernel<{dom}>":
+            traffic = pmc["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "kernel": f"conv_igemm_kernel<{dom}>", "launches_per_forward": d["n"] // 3,
             "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 2),
             "algorithmic_gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 3),

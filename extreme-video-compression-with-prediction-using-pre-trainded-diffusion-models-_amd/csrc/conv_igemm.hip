@@ -353,44 +353,60 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
 }
 
 // out = act((sum_z ws[z] + bias + res) * scale): deterministic split-K combine.
-// Block = one 64-pixel run x 64 channels (thread: channel tid & 63, rows tid >> 6, +4, ...): 256-byte coalesced
-// rows, and -- when `stats` is given -- the per-channel {sum, sumsq} of the run in the layout of the fused
-// conv epilogue (one writer per (run, channel): deterministic, no atomics).
-__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M,
-                                                                 int Co, const float* __restrict__ bias,
-                                                                 const float* __restrict__ res, int ld_res,
-                                                                 float scale, int act, float* __restrict__ out,
-                                                                 int ld_out, float* __restrict__ stats) {
-    __shared__ float red[2][4][64];
-    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+// Block = one 64-pixel run x 64 channels, 1024 threads (thread: channel tid & 63, rows tid >> 6, +16, ...):
+// 256-byte coalesced rows, 4 rows per thread so even the 8x8 layers (M = 64 B) expose enough loads in flight,
+// and -- when `stats` is given -- the per-channel {sum, sumsq} of the run in the layout of the fused conv
+// epilogue (one writer per (run, channel): deterministic, no atomics).
+__global__ __launch_bounds__(1024) void conv_splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M,
+                                                                  int Co, const float* __restrict__ bias,
+                                                                  const float* __restrict__ res, int ld_res,
+                                                                  float scale, int act, float* __restrict__ out,
+                                                                  int ld_out, float* __restrict__ stats) {
+    __shared__ float red[2][16][64];
+    const int l = threadIdx.x & 63;
+    const int c = blockIdx.y * 64 + l;
     const int rg = threadIdx.x >> 6;
     const int m_base = blockIdx.x * 64;
     const size_t total = (size_t)M * Co;
     float s_sum = 0.f, s_sq = 0.f;
     if (c < Co) {
         const float b = bias ? bias[c] : 0.f;
-        for (int r = rg; r < 64; r += 4) {
-            const int m = m_base + r;
-            if (m >= M) break;
-            const size_t i = (size_t)m * Co + c;
-            float v = 0.f;
-            for (int z = 0; z < splits; ++z) v += ws[(size_t)z * total + i];
-            v += b;
-            if (res) v += res[(size_t)m * ld_res + c];
-            v = act_fn(v * scale, act);
-            out[(size_t)m * ld_out + c] = v;
-            s_sum += v; s_sq += v * v;
+        float v[4];
+        size_t idx[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = m_base + rg + 16 * k;
+            ok[k] = m < M;
+            idx[k] = (size_t)(ok[k] ? m : 0) * Co + c;
+            v[k] = 0.f;
+        }
+        for (int z = 0; z < splits; ++z) {          // 4 independent load streams per thread
+            const float* w = ws + (size_t)z * total;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += w[idx[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) continue;
+            const int m = m_base + rg + 16 * k;
+            float o = v[k] + b;
+            if (res) o += res[(size_t)m * ld_res + c];
+            o = act_fn(o * scale, act);
+            out[(size_t)m * ld_out + c] = o;
+            s_sum += o; s_sq += o * o;
         }
     }
     if (stats) {
-        red[0][rg][threadIdx.x & 63] = s_sum;
-        red[1][rg][threadIdx.x & 63] = s_sq;
+        red[0][rg][l] = s_sum;
+        red[1][rg][l] = s_sq;
         __syncthreads();
         if (rg == 0 && c < Co) {
-            const int l = threadIdx.x;
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { a += red[0][k][l]; q += red[1][k][l]; }
             float* sp = stats + ((size_t)blockIdx.x * Co + c) * 2;
-            sp[0] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
-            sp[1] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+            sp[0] = a; sp[1] = q;
         }
     }
 }
@@ -548,7 +564,7 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     else launch_mode<1>(mode, grid, lds, st, k);
     if (hipGetLastError() != hipSuccess) return EVC_ELAUNCH;
     if (k.splits > 1) {
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((k.M + 63) / 64, (k.Co + 63) / 64), dim3(256), 0, st, ws,
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((k.M + 63) / 64, (k.Co + 63) / 64), dim3(1024), 0, st, ws,
                            k.splits, k.M, k.Co, a->bias, a->res, a->ld_res, a->out_scale, a->act_out, a->out,
                            a->ld_out, a->stats_out);
         if (hipGetLastError() != hipSuccess) return EVC_ELAUNCH;
