@@ -18,10 +18,15 @@ def init(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("EVC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
+    elif torch.cuda.is_available() and os.environ.get("EVC_DIST_SHARE_GPU") == "1":
+        # rehearsal on a 1-GPU box: several ranks share the visible GPUs, collectives go over gloo
+        n = torch.cuda.device_count()
+        torch.cuda.set_device(local % n)
+        device = torch.device("cuda", local % n)
     else:
         device = torch.device("cpu")
     if world > 1 and not dist.is_initialized():
