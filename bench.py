@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--sampler", default="DDPM", choices=["DDPM", "DDIM", "FPNDM"])
     ap.add_argument("--groups", type=int, default=2,
                     help="concurrent clip groups per GPU during generation (one HIP stream each)")
+    ap.add_argument("--preactivate", action="store_true",
+                    help="apply AdaGN+SiLU once per tensor in its own pass instead of inside the conv operand load")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -129,7 +131,7 @@ def main():
     sd_e = synthetic.elic_state_dict(3) if rank == 0 else None     # quality index 3 (q3)
     sd_d = D.broadcast_state_dict(sd_d, src=0, device=device, world=world)
     sd_e = D.broadcast_state_dict(sd_e, src=0, device=device, world=world)
-    net = ScoreNet(cfg, sd_d, device=device)
+    net = ScoreNet(cfg, sd_d, device=device, preactivate=a.preactivate)
     elic = ElicModel(sd_e, device=device)
     dec = ClipDecoder(net, elic, cfg, S.get_sampler(a.sampler), groups=a.groups)
 

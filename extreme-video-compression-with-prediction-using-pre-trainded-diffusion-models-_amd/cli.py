@@ -50,6 +50,9 @@ def build_parser():
     p.add_argument("--thresholds", type=float, nargs="+", default=None,
                    help="psnr policy: dB thresholds (reference sweeps LPIPS 0.30..0.03, city_sender.py:508)")
     p.add_argument("--synthetic", action="store_true", help="seeded stand-ins for missing checkpoints / data")
+    p.add_argument("--batch", type=int, default=8,
+                   help="mask policy: clips decoded together per GPU (the reference runs one clip at a time)")
+    p.add_argument("--groups", type=int, default=2, help="concurrent clip groups (HIP streams) inside a batch")
     return p
 
 
@@ -129,45 +132,75 @@ def main(argv=None):
     gen = torch.Generator(device=device).manual_seed(args.seed + rank)
     thresholds = args.thresholds if args.policy == "psnr" and args.thresholds else [0.0]
     t_start = time.time()
-    for vid in range(args.start_idx + lo, args.start_idx + hi):
-        out_root = os.path.join(args.output_path, f"output_{vid}")
-        gt = torch.from_numpy(np.asarray(data[vid], dtype=np.float32) / 255.0)          # (30,3,H,W)
-        all_psnr, all_bpp = [], []
+    vids = list(range(args.start_idx + lo, args.start_idx + hi))
+
+    def report(vid, q, thr, x, gt, bits, d, store):
+        bpp = sum(bits) / 128 / 128 / 30
+        ps = [cal_psnr(x[i], gt[i]) for i in range(30)]
+        print(f"[rank {rank}] video {vid} q{q} thr {thr:.2f}: d={list(d[:30])} BPP {bpp:.5f} PSNR {np.mean(ps):.3f}",
+              flush=True)
+        store.setdefault(vid, ([], []))
+        store[vid][0].append(ps); store[vid][1].append(bpp)
+        g = np.concatenate(list(gt.transpose(0, 2, 3, 1)), axis=1)
+        xg = np.concatenate(list(x.transpose(0, 2, 3, 1)), axis=1)
+        save_output(g, xg, q, thr, vid, os.path.join(args.output_path, f"output_{vid}"))
+
+    store = {}
+    if args.policy == "mask":
+        # every clip has the same transmit mask (2 key frames, then generated): decode `--batch` clips per launch
+        # through the receiver (the path bench.py measures) instead of one clip at a time
+        from .decoder import all_generated_mask
+        from .elic import count_bits
+        mask = all_generated_mask()
         for q in args.q:
             model = models[q]
-            dec = ClipDecoder(net, model, cfg, S.get_sampler(args.sampler))
-            for thr in thresholds:
-                x_ge, bits, d = [], [], []
-                for f in (0, 1):                                    # key frames (city_sender.py:521-524)
-                    xh, b = inference(model, gt[f].to(device), args.patch)
-                    x_ge.append(xh[0]); bits.append(b); d.append(1)
-                while len(x_ge) < 30:                                # city_sender.py:534-548
-                    l = len(x_ge)
-                    cond = torch.stack(x_ge[-2:], 0)[None]
-                    pred = dec.generate(cond.contiguous(), generator=gen)[0]
-                    acc = 0
-                    for j in range(min(5, 30 - l)):
-                        ok = args.policy == "mask" or cal_psnr(pred[j].cpu().numpy(), gt[l + j].numpy()) >= thr
-                        if not ok:
-                            break
-                        x_ge.append(pred[j]); d.append(0); acc += 1
-                    if acc == 0:
-                        for f in (l, l + 1):
-                            if f < 30:
-                                xh, b = inference(model, gt[f].to(device), args.patch)
-                                x_ge.append(xh[0]); bits.append(b); d.append(1)
-                x = torch.stack(x_ge[:30], 0).cpu().numpy()
-                bpp = sum(bits) / 128 / 128 / 30
-                ps = [cal_psnr(x[i], gt[i].numpy()) for i in range(30)]
-                print(f"[rank {rank}] video {vid} q{q} thr {thr:.2f}: d={d[:30]} BPP {bpp:.5f} PSNR {np.mean(ps):.3f}",
-                      flush=True)
-                all_psnr.append(ps); all_bpp.append(bpp)
-                g = np.concatenate(list(gt.numpy().transpose(0, 2, 3, 1)), axis=1)
-                xg = np.concatenate(list(x.transpose(0, 2, 3, 1)), axis=1)
-                save_output(g, xg, q, thr, vid, out_root)
+            dec = ClipDecoder(net, model, cfg, S.get_sampler(args.sampler), groups=args.groups)
+            for b0 in range(0, len(vids), max(1, args.batch)):
+                chunk = vids[b0:b0 + max(1, args.batch)]
+                gt = torch.from_numpy(np.stack([np.asarray(data[v], dtype=np.float32) / 255.0 for v in chunk]))
+                keys, shape = [], None
+                for f in (0, 1):                                   # key frames (city_sender.py:521-524), batched
+                    pad = (-gt.shape[-1]) % args.patch, (-gt.shape[-2]) % args.patch
+                    xk = torch.nn.functional.pad(gt[:, f], (0, pad[0], 0, pad[1]))
+                    enc = model.compress(xk.to(device))
+                    keys.append(enc["strings"]); shape = enc["shape"]
+                frames = dec.decode(mask, keys, shape, generator=gen)[..., :gt.shape[-2], :gt.shape[-1]]
+                x_all = frames.cpu().numpy()
+                for j, vid in enumerate(chunk):
+                    bits = [count_bits([[[[p[j]] for p in sl] for sl in k[0]], [k[1][j]]]) for k in keys]
+                    report(vid, q, 0.0, x_all[j], gt[j].numpy(), bits, mask, store)
+    else:
+        for vid in vids:
+            gt = torch.from_numpy(np.asarray(data[vid], dtype=np.float32) / 255.0)          # (30,3,H,W)
+            for q in args.q:
+                model = models[q]
+                dec = ClipDecoder(net, model, cfg, S.get_sampler(args.sampler))
+                for thr in thresholds:
+                    x_ge, bits, d = [], [], []
+                    for f in (0, 1):                                    # key frames (city_sender.py:521-524)
+                        xh, b = inference(model, gt[f].to(device), args.patch)
+                        x_ge.append(xh[0]); bits.append(b); d.append(1)
+                    while len(x_ge) < 30:                                # city_sender.py:534-548
+                        l = len(x_ge)
+                        cond = torch.stack(x_ge[-2:], 0)[None]
+                        pred = dec.generate(cond.contiguous(), generator=gen)[0]
+                        acc = 0
+                        for j in range(min(5, 30 - l)):
+                            if cal_psnr(pred[j].cpu().numpy(), gt[l + j].numpy()) < thr:   # decide_5to5, :353-374
+                                break
+                            x_ge.append(pred[j]); d.append(0); acc += 1
+                        if acc == 0:
+                            for f in (l, l + 1):
+                                if f < 30:
+                                    xh, b = inference(model, gt[f].to(device), args.patch)
+                                    x_ge.append(xh[0]); bits.append(b); d.append(1)
+                    x = torch.stack(x_ge[:30], 0).cpu().numpy()
+                    report(vid, q, thr, x, gt.numpy(), bits, d, store)
+    for vid, (ps, bpps) in store.items():
+        out_root = os.path.join(args.output_path, f"output_{vid}")
         os.makedirs(out_root, exist_ok=True)
-        np.save(os.path.join(out_root, f"psnr_{vid}.npy"), np.asarray(all_psnr))
-        np.save(os.path.join(out_root, f"bpp_{vid}.npy"), np.asarray(all_bpp))
+        np.save(os.path.join(out_root, f"psnr_{vid}.npy"), np.asarray(ps))
+        np.save(os.path.join(out_root, f"bpp_{vid}.npy"), np.asarray(bpps))
     D.barrier()
     if rank == 0:
         print(f"done in {time.time() - t_start:.1f}s")

@@ -65,12 +65,44 @@ def forward_probe(Bs):
                       f"{t / B:.1f} ms/sample, host enqueue {host_ms:.1f} ms", flush=True)
 
 
+def layer_probe(B):
+    """Per conv shape inside a real forward: launches, time, TFLOP/s (HIP events around every conv launch)."""
+    import collections
+    from oracle.scorenet import Dims, seeded_params
+    from evc_amd.config import default_config as make_config
+    from evc_amd.scorenet import ScoreNet
+    net = ScoreNet(make_config(192, 192, 128), seeded_params(Dims(), 1234))
+    x, c = torch.randn(B, 15, 128, 128, device="cuda"), torch.randn(B, 6, 128, 128, device="cuda")
+    net.forward_label(x, 500, c)
+    torch.cuda.synchronize()
+    prof = []
+    L.CONV_PROFILE = prof
+    for _ in range(3):
+        net.forward_label(x, 500, c)
+    L.CONV_PROFILE = None
+    torch.cuda.synchronize()
+    agg = collections.OrderedDict()
+    for r in prof:
+        k = r["shape"] + (r["split"],)
+        a = agg.setdefault(k, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += r["e0"].elapsed_time(r["e1"]); a[2] += r["flops"]
+    tot = sum(a[1] for a in agg.values()) / 3
+    print(f"conv total {tot:.2f} ms/forward at B={B}")
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        Bq, H, W, Ci, Co, K, sp = k
+        print(f"  {H:3d}x{W:<3d} {Ci:4d}->{Co:<4d} k{K} splitK={int(sp)} : n={a[0] // 3:2d}  {a[1] / 3:6.3f} ms/fwd "
+              f"({100 * a[1] / 3 / tot:4.1f}%)  {a[2] / a[1] / 1e9:6.1f} TF/s", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--conv", type=int, default=0)
     ap.add_argument("--forward", type=int, nargs="*", default=[])
+    ap.add_argument("--layers", type=int, default=0)
     a = ap.parse_args()
     if a.conv:
         conv_probe(a.conv)
     if a.forward:
         forward_probe(a.forward)
+    if a.layers:
+        layer_probe(a.layers)
