@@ -37,6 +37,9 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #ifndef EVC_CONV_ABLATE
 #define EVC_CONV_ABLATE 0      // DIAGNOSTIC ONLY (wrong results): bit 0 = skip the weight DMA, bit 1 = skip the activation path
 #endif
+#ifndef EVC_CONV_TM1
+#define EVC_CONV_TM1 1         // 1: grids with < 64 tiles of 128 pixels use 64-pixel tiles (0 disables, for A/B)
+#endif
 #ifndef EVC_CONV_PLAIN_DMA
 #define EVC_CONV_PLAIN_DMA 0   // 1: in plain mode the activation tile also goes global -> LDS by DMA (out-of-image lanes
                                // read a zero page). Measured equal to register staging on MI355X; kept as an option.
@@ -46,7 +49,7 @@ namespace {
 
 __device__ float g_zero_page[64];   // source of out-of-image taps for the DMA path (zero-initialised)
 
-constexpr int BM = 128;      // pixels per workgroup tile
+constexpr int BM_MAX = 128;  // pixels per workgroup tile: 64 * TM (TM = 32-row MFMA tiles per wave, 1 or 2)
 constexpr int KC = 16;       // channels per K step (one 64-byte LDS row)
 
 // load-transform modes (template parameter of the kernel)
@@ -87,18 +90,19 @@ __device__ __forceinline__ float4 transform(float4 v, const float4& a, const flo
     return v;
 }
 
-// 4 k-pairs x 2 x TN MFMAs on one 8-deep k group; consecutive MFMAs go to different accumulators.
-template <int TN>
-__device__ __forceinline__ void mfma_group(f32x16 (&acc)[2][TN], const float4 (&a)[2], const float4 (&b)[TN]) {
+// 4 k-pairs x TM x TN MFMAs on one 8-deep k group; consecutive MFMAs go to different accumulators.
+template <int TM, int TN>
+__device__ __forceinline__ void mfma_group(f32x16 (&acc)[TM][TN], const float4 (&a)[TM], const float4 (&b)[TN]) {
 #define EVC_MFMA_E(e)                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)       \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)      \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].e, b[j].e, acc[i][j], 0, 0, 0);
     EVC_MFMA_E(x) EVC_MFMA_E(y) EVC_MFMA_E(z) EVC_MFMA_E(w)
 #undef EVC_MFMA_E
 }
 
-template <int TN, int MODE>
+template <int TM, int TN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
+    constexpr int BM = 64 * TM;
     constexpr int BN = 64 * TN;
     constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
     constexpr bool DMA_A = EVC_CONV_PLAIN_DMA && MODE == MODE_PLAIN;
@@ -122,10 +126,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     const int k4 = tid & 3;
     const int padH = p.KH >> 1, padW = p.KW >> 1;
     const int Ct = p.C0 + p.C1;
-    unsigned off0[2], off1[2], okmask[2];     // byte offsets of the output pixel in src0 / src1, tap-valid bits
-    int rb[2], a_lds[2];
+    unsigned off0[TM], off1[TM], okmask[TM];  // byte offsets of the output pixel in src0 / src1, tap-valid bits
+    int rb[TM], a_lds[TM];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
         const int row = (tid >> 2) + 64 * i;
         const int m = m0 + row;
         const bool valid = m < p.M;
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     // wave row offsets are multiples of 16 rows, so the XOR term depends on the lane only.
     const int fsw = (l31 >> 2) & 3;
     const int rd0 = 4 * ((0 + half) ^ fsw), rd1 = 4 * ((2 + half) ^ fsw);
-    const int a_rd = (wm * 64 + l31) * KC, w_rd = (wn * 32 * TN + l31) * KC;
+    const int a_rd = (wm * 32 * TM + l31) * KC, w_rd = (wn * 32 * TN + l31) * KC;
 
     // ---- "next step" cursor, advanced incrementally (chunk-major, taps inner) ----
     int c_chunk, c_ty, c_tx;
@@ -168,13 +172,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         c_ty = tap / p.KW;
         c_tx = tap - c_ty * p.KW;
     }
-    float4 areg[2], ca[2], cs[2];
-    bool aok[2];
+    float4 areg[TM], ca[TM], cs[TM];
+    bool aok[TM];
 
     auto load_coefs = [&]() {
         if (HAS_COEF) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TM; ++i) {
                 const size_t co = (size_t)rb[i] * Ct + c_chunk * KC + 4 * k4;
                 ca[i] = *reinterpret_cast<const float4*>(p.coef_a + co);
                 cs[i] = *reinterpret_cast<const float4*>(p.coef_s + co);
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         if (DMA_A) {
             float* al = As + buf * BM * KC;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TM; ++i) {
                 const bool ok = (okmask[i] >> tap) & 1u;
                 const char* g = ok ? src + ((first ? off0[i] : off1[i]) + (unsigned)delta)
                                    : reinterpret_cast<const char*>(g_zero_page) + 16 * k4;
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TM; ++i) {
                 aok[i] = (okmask[i] >> tap) & 1u;
                 const unsigned o = aok[i] ? (first ? off0[i] : off1[i]) + (unsigned)delta : safe;
                 areg[i] = *reinterpret_cast<const float4*>(src + o);
@@ -224,13 +228,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         if (DMA_A) return;
         float* A = As + buf * BM * KC;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
             *reinterpret_cast<float4*>(A + a_lds[i]) = transform<MODE>(areg[i], ca[i], cs[i], aok[i]);
     };
 
-    f32x16 acc[2][TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -260,27 +264,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
 
         const float* Ab = As + buf * BM * KC + a_rd;
         const float* Wb = Ws + buf * BN * KC + w_rd;
-        float4 a0[2], b0[TN], a1[2], b1[TN];
+        float4 a0[TM], b0[TN], a1[TM], b1[TN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a0[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * KC + rd0);
+        for (int i = 0; i < TM; ++i) a0[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * KC + rd0);
 #pragma unroll
         for (int j = 0; j < TN; ++j) b0[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * KC + rd0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a1[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * KC + rd1);
+        for (int i = 0; i < TM; ++i) a1[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * KC + rd1);
 #pragma unroll
         for (int j = 0; j < TN; ++j) b1[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * KC + rd1);
-        mfma_group<TN>(acc, a0, b0);
+        mfma_group<TM, TN>(acc, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
 #if !(EVC_CONV_ABLATE & 2)
         store_a(buf ^ 1);            // producer work for the next step sits among the second half of the MFMAs
 #endif
-        mfma_group<TN>(acc, a1, b1);
+        mfma_group<TM, TN>(acc, a1, b1);
         __syncthreads();             // also drains the W DMA (vmcnt) before anyone reads the new buffers
     }
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
     const bool partial = p.splits > 1;
-    const int mw = m0 + wm * 64 + 4 * half;
+    const int mw = m0 + wm * 32 * TM + 4 * half;
     const int cw = n0 + wn * 32 * TN + l31;
     if (m0 + BM <= p.M && n0 + BN <= p.Co) {
         // full tile: straight-line code, residual loads batched ahead of the arithmetic
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
             const float bias = (!partial && p.bias) ? p.bias[co] : 0.f;
             float st_sum = 0.f, st_sq = 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TM; ++i) {
                 const int mb = mw + i * 32;
                 if (partial) {
                     float* o = p.ws + ((size_t)split * p.M + mb) * p.Co + co;
@@ -314,13 +318,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
                     }
                 }
             }
-            // fused GroupNorm moments: this wave holds channel `co` of a whole 64-pixel run (lanes l and l^32
+            // fused GroupNorm moments: this wave holds channel `co` of a whole 32*TM-pixel run (lanes l and l^32
             // share the channel); one writer per (run, channel) => deterministic, no atomics.
             if (!partial && p.stats) {
                 st_sum += __shfl_xor(st_sum, 32);
                 st_sq += __shfl_xor(st_sq, 32);
                 if (half == 0) {
-                    float* sp = p.stats + ((size_t)((m0 >> 6) + wm) * p.Co + co) * 2;
+                    float* sp = p.stats + ((size_t)(m0 / (32 * TM) + wm) * p.Co + co) * 2;
                     sp[0] = st_sum; sp[1] = st_sq;
                 }
             }
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
             if (co >= p.Co) continue;
             const float bias = (!partial && p.bias) ? p.bias[co] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2);
@@ -467,37 +471,54 @@ static int conv_validate(const evc_conv_args* a) {
     return EVC_OK;
 }
 
-// Split-K choice.  Measured on MI355X (tools/conv_bench.hip): a workgroup alone on a CU is latency-bound
-// (~3.1 us per K-step against 1.4 us of MFMA time), two per CU take ~3.8 us per step pair, so small grids want
-// ~2.5 resident workgroups per CU (640 in all); a grid that already offers 384 tiles is left alone because the
-// slab write + combine traffic then costs more than the idle CUs.  At least 8 K-steps per split keep the
-// prologue / epilogue amortised.
-extern "C" int evc_conv_choose_splits(const evc_conv_args* a) {
-    if (conv_validate(a) != EVC_OK) return EVC_EINVAL;
-    if (a->splits > 0) return a->splits;
+// Tile configuration + split-K choice.  Measured on MI355X (tools/conv_bench.hip): a workgroup alone on a CU is
+// latency-bound (~3.1 us per K-step against 1.4 us of MFMA time), two per CU take ~3.8 us per step pair, so small
+// grids want ~2.5 resident workgroups per CU (640 in all).  A grid that offers >= 384 tiles is left alone, smaller
+// ones split K (at least 8 K-steps per split keep prologue / epilogue amortised).  Very small grids (< 64 tiles
+// of 128 pixels: the 8x8 layers) use the 64-pixel tile (TM = 1) first: half the split factor means half the slab
+// write + combine traffic and no half-empty tiles (A/B: 8x8 768->768 58 -> 69 TFLOP/s; on mid-size grids such
+// as 32x32 576->576 the smaller tile loses, 92 -> 84, so it is not used there).
+struct TileCfg { int tm, tn, bm, bn; long long tiles; int splits; };
+
+static TileCfg conv_tile_cfg(const evc_conv_args* a) {
+    TileCfg c;
     const long long M = (long long)a->B * a->H * a->W;
     const int CoPad = evc_conv_co_pad(a->Co);
-    const int BN = 64 * pick_tn(CoPad);
-    const long long tiles = ((M + BM - 1) / BM) * (CoPad / BN);
+    c.tn = pick_tn(CoPad);
+    c.bn = 64 * c.tn;
+    const long long ntile = CoPad / c.bn;
+    c.tm = (!EVC_CONV_TM1 || ((M + 127) / 128) * ntile >= 64) ? 2 : 1;
+    c.bm = 64 * c.tm;
+    c.tiles = ((M + c.bm - 1) / c.bm) * ntile;
     const int nsteps = a->KH * a->KW * ((a->C0 + a->C1) / KC);
-    if (tiles >= 384) return 1;
-    long long splits = (640 + tiles / 2) / tiles;
-    const int max_by_steps = nsteps / 8 > 0 ? nsteps / 8 : 1;
-    if (splits > max_by_steps) splits = max_by_steps;
-    if (splits > 32) splits = 32;
-    if (splits < 1) splits = 1;
-    return (int)splits;
+    long long splits = 1;
+    if (a->splits > 0) splits = a->splits;
+    else if (c.tiles < 384) {
+        splits = (640 + c.tiles / 2) / c.tiles;
+        const int max_by_steps = nsteps / 8 > 0 ? nsteps / 8 : 1;
+        if (splits > max_by_steps) splits = max_by_steps;
+        if (splits > 32) splits = 32;
+        if (splits < 1) splits = 1;
+    }
+    c.splits = (int)splits;
+    return c;
+}
+
+extern "C" int evc_conv_choose_splits(const evc_conv_args* a) {
+    if (conv_validate(a) != EVC_OK) return EVC_EINVAL;
+    return conv_tile_cfg(a).splits;
 }
 
 extern "C" int evc_conv_stats_splits(const evc_conv_args* a) {
     if (conv_validate(a) != EVC_OK) return 0;
     const int HW = a->H * a->W;
     if (HW % 64 != 0) return 0;
-    if (evc_conv_choose_splits(a) > 1) return HW / 64;        // produced by the split-K combine kernel
+    const TileCfg c = conv_tile_cfg(a);
+    if (c.splits > 1) return HW / 64;                          // produced by the split-K combine kernel (64-pixel runs)
     const long long M = (long long)a->B * HW;
     const int CoPad = evc_conv_co_pad(a->Co);
-    if (M % BM != 0 || a->Co != CoPad || a->Co % (64 * pick_tn(CoPad)) != 0) return 0;
-    return HW / 64;                                            // produced by the conv epilogue (full tiles only)
+    if (M % c.bm != 0 || a->Co != CoPad || a->Co % c.bn != 0) return 0;
+    return HW / (32 * c.tm);                                   // produced by the conv epilogue: one run per wave row
 }
 
 extern "C" long long evc_conv_workspace_bytes(const evc_conv_args* a) {
@@ -509,14 +530,14 @@ extern "C" long long evc_conv_workspace_bytes(const evc_conv_args* a) {
 
 extern "C" int evc_conv_set_wave_layout(int) { return EVC_OK; }   // retired tuning hook (kept for ABI stability)
 
-template <int TN>
+template <int TM, int TN>
 static void launch_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
     switch (mode) {
-        case MODE_AFFINE: hipLaunchKernelGGL((conv_igemm_kernel<TN, MODE_AFFINE>), grid, dim3(256), lds, st, k); break;
-        case MODE_AFFINE_SILU: hipLaunchKernelGGL((conv_igemm_kernel<TN, MODE_AFFINE_SILU>), grid, dim3(256), lds, st, k); break;
-        case MODE_SILU: hipLaunchKernelGGL((conv_igemm_kernel<TN, MODE_SILU>), grid, dim3(256), lds, st, k); break;
-        case MODE_RELU: hipLaunchKernelGGL((conv_igemm_kernel<TN, MODE_RELU>), grid, dim3(256), lds, st, k); break;
-        default: hipLaunchKernelGGL((conv_igemm_kernel<TN, MODE_PLAIN>), grid, dim3(256), lds, st, k); break;
+        case MODE_AFFINE: hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, MODE_AFFINE>), grid, dim3(256), lds, st, k); break;
+        case MODE_AFFINE_SILU: hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, MODE_AFFINE_SILU>), grid, dim3(256), lds, st, k); break;
+        case MODE_SILU: hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, MODE_SILU>), grid, dim3(256), lds, st, k); break;
+        case MODE_RELU: hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, MODE_RELU>), grid, dim3(256), lds, st, k); break;
+        default: hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, MODE_PLAIN>), grid, dim3(256), lds, st, k); break;
     }
 }
 
@@ -546,7 +567,8 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     if (a->KH * a->KW > 32) return EVC_EUNSUPPORTED;   // tap-valid bit mask is 32 bits wide
     k.nchunk = (a->C0 + a->C1) / KC;
     k.nsteps = a->KH * a->KW * k.nchunk;
-    k.splits = evc_conv_choose_splits(a);
+    const TileCfg cfg = conv_tile_cfg(a);
+    k.splits = cfg.splits;
     k.steps_per_split = (k.nsteps + k.splits - 1) / k.splits;
     k.splits = (k.nsteps + k.steps_per_split - 1) / k.steps_per_split;   // no empty splits
     k.ws = ws;
@@ -554,14 +576,18 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     k.stats = k.splits > 1 ? nullptr : a->stats_out;   // with split-K the combine kernel writes them
     if (a->stats_out && evc_conv_stats_splits(a) == 0) return EVC_EINVAL;
 
-    const int tn = pick_tn(k.CoPad);
-    const int BN = 64 * tn;
-    dim3 grid((k.M + BM - 1) / BM, k.CoPad / BN, k.splits);
-    const size_t lds = (size_t)2 * (BM + BN) * KC * sizeof(float);
+    dim3 grid((k.M + cfg.bm - 1) / cfg.bm, k.CoPad / cfg.bn, k.splits);
+    const size_t lds = (size_t)2 * (cfg.bm + cfg.bn) * KC * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (tn == 3) launch_mode<3>(mode, grid, lds, st, k);
-    else if (tn == 2) launch_mode<2>(mode, grid, lds, st, k);
-    else launch_mode<1>(mode, grid, lds, st, k);
+    if (cfg.tm == 2) {
+        if (cfg.tn == 3) launch_mode<2, 3>(mode, grid, lds, st, k);
+        else if (cfg.tn == 2) launch_mode<2, 2>(mode, grid, lds, st, k);
+        else launch_mode<2, 1>(mode, grid, lds, st, k);
+    } else {
+        if (cfg.tn == 3) launch_mode<1, 3>(mode, grid, lds, st, k);
+        else if (cfg.tn == 2) launch_mode<1, 2>(mode, grid, lds, st, k);
+        else launch_mode<1, 1>(mode, grid, lds, st, k);
+    }
     if (hipGetLastError() != hipSuccess) return EVC_ELAUNCH;
     if (k.splits > 1) {
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((k.M + 63) / 64, (k.Co + 63) / 64), dim3(1024), 0, st, ws,

@@ -97,16 +97,17 @@ typedef struct {
     int B; int H; int W; int Co; int KH; int KW;
     int splits;            /* 0 = choose automatically */
     float* stats_out;      /* optional: per-channel moments of `out`, fused into the epilogue, in the layout of
-                              evc_chan_stats_f32 with nsplit = H*W/64 ([B][H*W/64][Co][2] = {sum, sumsq} of each
-                              64-pixel run). Only honoured when evc_conv_stats_splits() > 0; else must be NULL. */
+                              evc_chan_stats_f32 with nsplit = evc_conv_stats_splits() ([B][nsplit][Co][2] = {sum, sumsq}
+                              of each pixel run). Only honoured when that is > 0; else must be NULL. */
 } evc_conv_args;
 int evc_conv_co_pad(int Co);
 long long evc_conv_packed_floats(int Co, int Ci, int KH, int KW);
 /* w: [Co][Ci][KH][KW] (PyTorch Conv2d layout, device) -> packed (device). */
 int evc_conv_pack_weights_f32(const float* w, float* packed, int Co, int Ci, int KH, int KW, void* stream);
 int evc_conv_choose_splits(const evc_conv_args* a);
-/* H*W/64 when the fused moments are available for these arguments (H*W % 64 == 0 and either split-K -- the combine
- * kernel writes them -- or only full 128 x 64*TN tiles), else 0: the caller then runs evc_chan_stats_f32 instead. */
+/* The number of pixel runs per image (H*W/64 or H*W/32) for which the fused moments will be written, when they are
+ * available for these arguments (H*W % 64 == 0 and either split-K -- the combine kernel writes them -- or only full
+ * tiles), else 0: the caller then runs evc_chan_stats_f32 on the output instead. */
 int evc_conv_stats_splits(const evc_conv_args* a);
 /* Tuning hook: workgroup wave layout of the Co%192==0 kernel: 0 automatic, 1 = 4 waves (wave tile 64x96),
  * 2 = 8 waves (wave tile 32x96).  Results are identical; only speed differs. */

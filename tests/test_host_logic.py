@@ -87,7 +87,9 @@ def test_conv_dispatch_queries_without_gpu():
     q = lib.conv_fused_stats_splits
     assert q(9, 128, 128, 192, 192, 3, 3) == 128 * 128 // 64      # full 128x192 tiles, no split-K
     assert q(9, 8, 8, 768, 768, 3, 3) == 1                         # small grid -> split-K -> moments from the combine kernel
+    assert q(1, 16, 16, 192, 192, 3, 3, splits=1) == 16 * 16 // 32  # tiny grid -> 64-pixel tiles: 32-pixel runs
     assert q(9, 4, 4, 768, 768, 3, 3) == 0                         # HW not a multiple of the 64-pixel run
     assert q(2, 16, 16, 32, 96, 3, 3, splits=1) == 0               # Co not a whole number of column tiles
-    assert q(1, 8, 24, 32, 192, 3, 3, splits=1) == 0               # M not a multiple of the 128-pixel tile
+    assert q(1, 8, 24, 32, 192, 3, 3, splits=1) == 6               # 192 pixels = 3 tiles of 64 -> six 32-pixel runs
+    assert q(1, 8, 20, 32, 192, 3, 3, splits=1) == 0               # H*W not a multiple of 64
     assert q(1, 128, 128, 24, 192, 3, 3) == 0                      # invalid (channels % 16) -> never fused

@@ -19,7 +19,8 @@ int main(int argc, char** argv) {
     std::vector<Shape> shapes = {{8, 128, 192, 192, 3, 0}, {8, 128, 192, 192, 3, 1}, {9, 128, 192, 192, 3, 1},
                                  {8, 128, 384, 192, 3, 1}, {8, 64, 384, 384, 3, 0}, {8, 64, 384, 384, 3, 1},
                                  {9, 64, 384, 384, 3, 1}, {8, 32, 576, 576, 3, 1}, {9, 16, 576, 576, 3, 1},
-                                 {9, 8, 768, 768, 3, 1}};
+                                 {9, 8, 768, 768, 3, 1}, {9, 64, 192, 192, 3, 1}, {9, 32, 384, 384, 3, 1},
+                                 {9, 32, 576, 576, 3, 1}, {9, 8, 768, 768, 1, 0}, {9, 64, 384, 192, 3, 1}};
     printf("# conv_bench layout=%d iters=%d\n", layout, iters);
     for (size_t si = 0; si < shapes.size(); ++si) {
         if (only >= 0 && (int)si != only) continue;
