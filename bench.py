@@ -160,6 +160,15 @@ def main():
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
     assert frames.shape == (a.clips, 30, 3, 128, 128) and bool(torch.isfinite(frames).all())
 
+    # how much of a step is ELIC key-frame decoding (latency-bound: 10 host round trips per batch)
+    torch.cuda.synchronize()
+    te = time.perf_counter()
+    ys = [[[s_ for f in range(2) for s_ in key_strings[f][0][i][p]] for p in range(2)] for i in range(5)]
+    zs = [s_ for f in range(2) for s_ in key_strings[f][1]]
+    elic.decompress([ys, zs], shape)
+    torch.cuda.synchronize()
+    elic_ms = (time.perf_counter() - te) * 1e3
+
     n_frames = world * a.clips * 30 * a.steps
     value = n_frames / elapsed
     fwd_per_chunk = {"DDPM": a.subsample + 1, "DDIM": a.subsample + 1, "FPNDM": 12 + (a.subsample - 3)}[a.sampler]
@@ -172,7 +181,8 @@ def main():
                       "parallelism": f"clip-sharded dp{world}, no data-path collective; {a.groups} concurrent clip "
                                      f"group(s) per GPU",
                       "weights": "seeded random, reference architecture (262.1M + ELIC)"},
-           "whole_path_tflops_per_gpu": round(flop_per_step_gpu * a.steps / elapsed / 1e12, 2)}
+           "whole_path_tflops_per_gpu": round(flop_per_step_gpu * a.steps / elapsed / 1e12, 2),
+           "elic_keyframe_decode_ms_per_step": round(elic_ms, 1)}
     if rank == 0:
         out["roofline"] = roofline_leg(net, a.clips, device)
         if world == 1 and not a.no_cpu_baseline:

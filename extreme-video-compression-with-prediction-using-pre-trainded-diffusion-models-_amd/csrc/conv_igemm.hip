@@ -528,8 +528,6 @@ extern "C" long long evc_conv_workspace_bytes(const evc_conv_args* a) {
     return (long long)s * a->B * a->H * a->W * a->Co * (long long)sizeof(float);
 }
 
-extern "C" int evc_conv_set_wave_layout(int) { return EVC_OK; }   // retired tuning hook (kept for ABI stability)
-
 template <int TM, int TN>
 static void launch_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
     switch (mode) {

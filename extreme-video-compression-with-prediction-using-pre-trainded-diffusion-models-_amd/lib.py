@@ -59,7 +59,6 @@ HIP_SYMBOLS = {
     "evc_conv_packed_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
     "evc_conv_pack_weights_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "evc_conv_choose_splits": (c_int, [POINTER(ConvArgs)]),
-    "evc_conv_set_wave_layout": (c_int, [c_int]),
     "evc_conv_stats_splits": (c_int, [POINTER(ConvArgs)]),
     "evc_conv_workspace_bytes": (c_longlong, [POINTER(ConvArgs)]),
     "evc_conv2d_nhwc_f32": (c_int, [POINTER(ConvArgs), c_void_p, c_void_p]),
@@ -116,8 +115,6 @@ def hip_lib(require_device=True):
     global _hip
     if _hip is None:
         _hip = _load(HIP_SO, HIP_SYMBOLS, "libevc_hip.so")
-        if os.environ.get("EVC_CONV_LAYOUT"):
-            _hip.evc_conv_set_wave_layout(int(os.environ["EVC_CONV_LAYOUT"]))
     if require_device:
         if not torch.cuda.is_available():
             raise EvcLibraryError("no HIP device visible: the evc_amd compute path is gfx950-only (no CPU fallback)")

@@ -109,9 +109,6 @@ int evc_conv_choose_splits(const evc_conv_args* a);
  * available for these arguments (H*W % 64 == 0 and either split-K -- the combine kernel writes them -- or only full
  * tiles), else 0: the caller then runs evc_chan_stats_f32 on the output instead. */
 int evc_conv_stats_splits(const evc_conv_args* a);
-/* Tuning hook: workgroup wave layout of the Co%192==0 kernel: 0 automatic, 1 = 4 waves (wave tile 64x96),
- * 2 = 8 waves (wave tile 32x96).  Results are identical; only speed differs. */
-int evc_conv_set_wave_layout(int layout);
 long long evc_conv_workspace_bytes(const evc_conv_args* a);
 int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stream);
 
