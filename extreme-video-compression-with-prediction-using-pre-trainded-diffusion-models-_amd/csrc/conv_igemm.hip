@@ -37,6 +37,13 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #ifndef EVC_CONV_ABLATE
 #define EVC_CONV_ABLATE 0      // DIAGNOSTIC ONLY (wrong results): bit 0 = skip the weight DMA, bit 1 = skip the activation path
 #endif
+#ifndef EVC_CONV_ROWREUSE
+#define EVC_CONV_ROWREUSE 0    // 1: 3x3 convs on row-aligned tiles stage the activation once per kernel row instead of once
+                               // per tap (conv_rowreuse_kernel).  Correct (full GPU suite passes with it), but measured on
+                               // MI355X: +4-5 % only for GroupNorm+SiLU convs on full grids at B=8 (103 -> 108 TFLOP/s),
+                               // neutral at B=9, -2..4 % on split-K layers (74 KB LDS -> 2 instead of 3 workgroups per CU),
+                               // so it is compiled out by default.
+#endif
 #ifndef EVC_CONV_TM1
 #define EVC_CONV_TM1 1         // 1: grids with < 64 tiles of 128 pixels use 64-pixel tiles (0 disables, for A/B)
 #endif
@@ -98,6 +105,87 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[TM][TN], const float4 (
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].e, b[j].e, acc[i][j], 0, 0, 0);
     EVC_MFMA_E(x) EVC_MFMA_E(y) EVC_MFMA_E(z) EVC_MFMA_E(w)
 #undef EVC_MFMA_E
+}
+
+// Epilogue shared by the convolution kernels.  C/D map of the 32x32 MFMA: col = lane & 31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Fuses bias + residual + scale + activation and, for full tiles, the
+// per-channel GroupNorm moments of the output; split-K launches write raw partial sums to their slab instead.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][TN], int m0, int n0, int split,
+                                              int wm, int wn, int l31, int half) {
+    constexpr int BM = 64 * TM;
+    constexpr int BN = 64 * TN;
+    const bool partial = p.splits > 1;
+    const int mw = m0 + wm * 32 * TM + 4 * half;
+    const int cw = n0 + wn * 32 * TN + l31;
+    if (m0 + BM <= p.M && n0 + BN <= p.Co) {
+        // full tile: straight-line code, residual loads batched ahead of the arithmetic
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int co = cw + j * 32;
+            const float bias = (!partial && p.bias) ? p.bias[co] : 0.f;
+            float st_sum = 0.f, st_sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mb = mw + i * 32;
+                if (partial) {
+                    float* o = p.ws + ((size_t)split * p.M + mb) * p.Co + co;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * p.Co] = acc[i][j][r];
+                } else {
+                    float rv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+                    if (p.res) {
+                        const float* rp = p.res + (size_t)mb * p.ld_res + co;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) rv[r] = rp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ld_res];
+                    }
+                    float* o = p.out + (size_t)mb * p.ld_out + co;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = act_fn((acc[i][j][r] + bias + rv[r]) * p.out_scale, p.act_out);
+                        o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ld_out] = v;
+                        st_sum += v; st_sq += v * v;
+                    }
+                }
+            }
+            // fused GroupNorm moments: this wave holds channel `co` of a whole 32*TM-pixel run (lanes l and l^32
+            // share the channel); one writer per (run, channel) => deterministic, no atomics.
+            if (!partial && p.stats) {
+                st_sum += __shfl_xor(st_sum, 32);
+                st_sq += __shfl_xor(st_sq, 32);
+                if (half == 0) {
+                    float* sp = p.stats + ((size_t)(m0 / (32 * TM) + wm) * p.Co + co) * 2;
+                    sp[0] = st_sum; sp[1] = st_sq;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int co = cw + j * 32;
+            if (co >= p.Co) continue;
+            const float bias = (!partial && p.bias) ? p.bias[co] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (m >= p.M) continue;
+                    float v = acc[i][j][r];
+                    if (partial) {
+                        p.ws[((size_t)split * p.M + m) * p.Co + co] = v;
+                    } else {
+                        v += bias;
+                        if (p.res) v += p.res[(size_t)m * p.ld_res + co];
+                        v *= p.out_scale;
+                        p.out[(size_t)m * p.ld_out + co] = act_fn(v, p.act_out);
+                    }
+                }
+            }
+        }
+    }
 }
 
 template <int TM, int TN, int MODE>
@@ -282,79 +370,183 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         __syncthreads();             // also drains the W DMA (vmcnt) before anyone reads the new buffers
     }
 
-    // ---- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-    const bool partial = p.splits > 1;
-    const int mw = m0 + wm * 32 * TM + 4 * half;
-    const int cw = n0 + wn * 32 * TN + l31;
-    if (m0 + BM <= p.M && n0 + BN <= p.Co) {
-        // full tile: straight-line code, residual loads batched ahead of the arithmetic
+    conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
+}
+
+#if EVC_CONV_ROWREUSE
+// Row-reuse variant: same GEMM tiling, but the activation operand of one channel chunk is staged ONCE per kernel
+// row instead of once per tap.  Precondition (checked by the host): the 64*TM-pixel tile consists of whole image
+// rows (W divides 64*TM) and a split covers whole chunks (steps_per_split % (KH*KW) == 0).
+// Per chunk the LDS holds KH sub-tiles; sub-tile u, element j = act(affine(src[pixel m0+j shifted by (u-padH) rows]))
+// or 0 when that source row is outside the image.  Tap (u, v) reads sub-tile u at LDS rows j + (v - padW): the
+// horizontally shifted neighbour.  Lanes whose own pixel has no such neighbour inside the image row (x + v - padW
+// outside [0, W)) select 0 -- those are exactly the reads that would otherwise wrap into the adjacent image row or
+// the (unwritten) pad rows.  Producer work per chunk: KH row gathers + transforms + LDS writes instead of KH*KW.
+template <int TM, int TN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_rowreuse_kernel(ConvK p) {
+    constexpr int BM = 64 * TM;
+    constexpr int BN = 64 * TN;
+    constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int padH = p.KH >> 1, padW = p.KW >> 1;
+    const int sub_rows = BM + 2 * padW;
+    const int a_floats = p.KH * sub_rows * KC;      // one activation buffer (all sub-tiles of a chunk)
+    float* const As = smem;                         // [2][KH][sub_rows][16]
+    float* const Ws = smem + 2 * a_floats;          // [2][BN][16]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int split = blockIdx.z;
+    const int taps = p.KH * p.KW;
+    const int s_begin = split * p.steps_per_split;
+    const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
+    const int c_begin = s_begin / taps, c_end = s_end / taps;   // whole chunks by precondition
+
+    // ---- producer state: rows tid/4 (+64), 4-channel column k4 ----
+    const int k4 = tid & 3;
+    const int Ct = p.C0 + p.C1;
+    unsigned off0[TM], off1[TM], dyok[TM];
+    int rb[TM], prow[TM];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int co = cw + j * 32;
-            const float bias = (!partial && p.bias) ? p.bias[co] : 0.f;
-            float st_sum = 0.f, st_sq = 0.f;
+    for (int i = 0; i < TM; ++i) {
+        const int row = (tid >> 2) + 64 * i;
+        const int m = m0 + row;
+        const bool valid = m < p.M;
+        const int mm = valid ? m : 0;
+        const int b = mm / p.HW;
+        const int y = (mm - b * p.HW) / p.W;
+        rb[i] = b; prow[i] = row;
+        off0[i] = ((unsigned)mm * (unsigned)p.ld0 + 4u * k4) * 4u;
+        off1[i] = ((unsigned)mm * (unsigned)p.ld1 + 4u * k4) * 4u;
+        unsigned mask = 0;
+        for (int u = 0; u < p.KH; ++u) mask |= ((valid && y + u - padH >= 0 && y + u - padH < p.H) ? 1u : 0u) << u;
+        dyok[i] = mask;
+    }
+    // ---- consumer state: tile row of this lane's pixels and their x coordinate (tile starts at x = 0) ----
+    int rrow[TM], px[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        rrow[i] = wm * 32 * TM + 32 * i + l31;
+        px[i] = rrow[i] % p.W;
+    }
+    const int w_rd = (wn * 32 * TN + l31) * KC;
+    const int wsw = (l31 >> 2) & 3;                    // weight rows: tile / wave offsets are multiples of 16
+    const int wrd0 = 4 * ((0 + half) ^ wsw), wrd1 = 4 * ((2 + half) ^ wsw);
+
+    float4 areg[TM], ca[TM], cs[TM];
+    bool aok[TM];
+
+    auto load_coefs = [&](int chunk) {
+        if (HAS_COEF) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int mb = mw + i * 32;
-                if (partial) {
-                    float* o = p.ws + ((size_t)split * p.M + mb) * p.Co + co;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * p.Co] = acc[i][j][r];
-                } else {
-                    float rv[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-                    if (p.res) {
-                        const float* rp = p.res + (size_t)mb * p.ld_res + co;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) rv[r] = rp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ld_res];
-                    }
-                    float* o = p.out + (size_t)mb * p.ld_out + co;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = act_fn((acc[i][j][r] + bias + rv[r]) * p.out_scale, p.act_out);
-                        o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ld_out] = v;
-                        st_sum += v; st_sq += v * v;
-                    }
-                }
-            }
-            // fused GroupNorm moments: this wave holds channel `co` of a whole 32*TM-pixel run (lanes l and l^32
-            // share the channel); one writer per (run, channel) => deterministic, no atomics.
-            if (!partial && p.stats) {
-                st_sum += __shfl_xor(st_sum, 32);
-                st_sq += __shfl_xor(st_sq, 32);
-                if (half == 0) {
-                    float* sp = p.stats + ((size_t)(m0 / (32 * TM) + wm) * p.Co + co) * 2;
-                    sp[0] = st_sum; sp[1] = st_sq;
-                }
+                const size_t co = (size_t)rb[i] * Ct + chunk * KC + 4 * k4;
+                ca[i] = *reinterpret_cast<const float4*>(p.coef_a + co);
+                cs[i] = *reinterpret_cast<const float4*>(p.coef_s + co);
             }
         }
-    } else {
+    };
+    auto load_sub = [&](int chunk, int u) {            // gather kernel row u of `chunk` into registers
+        const int c = chunk * KC;
+        const bool first = c < p.C0;
+        const char* src = reinterpret_cast<const char*>(first ? p.src0 : p.src1);
+        const int ld = first ? p.ld0 : p.ld1;
+        const int cc = first ? c : c - p.C0;
+        const int delta = ((u - padH) * p.W * ld + cc) * 4;
+        const unsigned safe = (unsigned)(cc + 4 * k4) * 4u;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int co = cw + j * 32;
-            if (co >= p.Co) continue;
-            const float bias = (!partial && p.bias) ? p.bias[co] : 0.f;
+        for (int i = 0; i < TM; ++i) {
+            aok[i] = (dyok[i] >> u) & 1u;
+            const unsigned o = aok[i] ? (first ? off0[i] : off1[i]) + (unsigned)delta : safe;
+            areg[i] = *reinterpret_cast<const float4*>(src + o);
+        }
+    };
+    auto store_sub = [&](int abuf, int u) {
+        float* A = As + abuf * a_floats;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int lrow = u * sub_rows + padW + prow[i];
+            *reinterpret_cast<float4*>(A + lrow * KC + 4 * (k4 ^ ((lrow >> 2) & 3))) =
+                transform<MODE>(areg[i], ca[i], cs[i], aok[i]);
+        }
+    };
+    auto dma_w = [&](int chunk, int tap, int wbuf) {
+        const float* wt = p.w + ((size_t)(tap * p.nchunk + chunk) * p.CoPad + n0) * KC;
+        float* wl = Ws + wbuf * BN * KC;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void*)(wt + (size_t)(tid + 256 * j) * 4),
+                                             (lds_void*)(wl + (wave * 16 + 64 * j) * KC), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end) {
+        load_coefs(c_begin);
+        for (int u = 0; u < p.KH; ++u) { load_sub(c_begin, u); store_sub(0, u); }
+        dma_w(c_begin, 0, 0);
+    }
+    __syncthreads();
+
+    int wbuf = 0;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        const int abuf = (chunk - c_begin) & 1;
+        const bool more_chunks = chunk + 1 < c_end;
+        int ty = 0, tx = 0;
+        for (int t = 0; t < taps; ++t) {
+            // producer, next chunk: kernel row t is gathered at tap t (t < KH), coefficients once per chunk
+            const bool produce = more_chunks && t < p.KH;          // wave-uniform
+            if (produce) {
+                if (t == 0) load_coefs(chunk + 1);
+                load_sub(chunk + 1, t);
+            }
+            // weight slab of the next step (next tap of this chunk, or tap 0 of the next chunk)
+            const bool last_tap = t + 1 == taps;
+            if (!last_tap) dma_w(chunk, t + 1, wbuf ^ 1);
+            else if (more_chunks) dma_w(chunk + 1, 0, wbuf ^ 1);
+
+            const float* A = As + abuf * a_floats;
+            const float* Wb = Ws + wbuf * BN * KC + w_rd;
+            float4 a0[TM], b0[TN], a1[TM], b1[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (m >= p.M) continue;
-                    float v = acc[i][j][r];
-                    if (partial) {
-                        p.ws[((size_t)split * p.M + m) * p.Co + co] = v;
-                    } else {
-                        v += bias;
-                        if (p.res) v += p.res[(size_t)m * p.ld_res + co];
-                        v *= p.out_scale;
-                        p.out[(size_t)m * p.ld_out + co] = act_fn(v, p.act_out);
-                    }
-                }
+                const int lrow = ty * sub_rows + rrow[i] + tx;      // = + padW + (tx - padW)
+                const int f = (lrow >> 2) & 3;
+                const bool ok = (unsigned)(px[i] + tx - padW) < (unsigned)p.W;
+                float4 v0 = *reinterpret_cast<const float4*>(A + lrow * KC + 4 * ((0 + half) ^ f));
+                float4 v1 = *reinterpret_cast<const float4*>(A + lrow * KC + 4 * ((2 + half) ^ f));
+                a0[i].x = ok ? v0.x : 0.f; a0[i].y = ok ? v0.y : 0.f; a0[i].z = ok ? v0.z : 0.f; a0[i].w = ok ? v0.w : 0.f;
+                a1[i].x = ok ? v1.x : 0.f; a1[i].y = ok ? v1.y : 0.f; a1[i].z = ok ? v1.z : 0.f; a1[i].w = ok ? v1.w : 0.f;
             }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                b0[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * KC + wrd0);
+                b1[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * KC + wrd1);
+            }
+            mfma_group<TM, TN>(acc, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (produce) store_sub(abuf ^ 1, t);
+            mfma_group<TM, TN>(acc, a1, b1);
+            __syncthreads();
+            wbuf ^= 1;
+            if (++tx == p.KW) { tx = 0; ++ty; }
         }
     }
+    conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
 }
+
+#endif  // EVC_CONV_ROWREUSE
 
 // out = act((sum_z ws[z] + bias + res) * scale): deterministic split-K combine.
 // Block = one 64-pixel run x 64 channels, 1024 threads (thread: channel tid & 63, rows tid >> 6, +16, ...):
@@ -478,7 +670,7 @@ static int conv_validate(const evc_conv_args* a) {
 // of 128 pixels: the 8x8 layers) use the 64-pixel tile (TM = 1) first: half the split factor means half the slab
 // write + combine traffic and no half-empty tiles (A/B: 8x8 768->768 58 -> 69 TFLOP/s; on mid-size grids such
 // as 32x32 576->576 the smaller tile loses, 92 -> 84, so it is not used there).
-struct TileCfg { int tm, tn, bm, bn; long long tiles; int splits; };
+struct TileCfg { int tm, tn, bm, bn; long long tiles; int splits; int reuse; int steps_per_split; };
 
 static TileCfg conv_tile_cfg(const evc_conv_args* a) {
     TileCfg c;
@@ -501,6 +693,20 @@ static TileCfg conv_tile_cfg(const evc_conv_args* a) {
         if (splits < 1) splits = 1;
     }
     c.splits = (int)splits;
+    // Row-reuse kernel: multi-tap filters whose tiles are whole image rows; a split must cover whole chunks, so
+    // round the steps per split up to a multiple of the tap count (the effective split count may shrink).
+    c.reuse = 0;
+#if EVC_CONV_ROWREUSE
+    const int taps = a->KH * a->KW;
+    if (taps > 1 && a->KH <= 3 && a->KW <= 3 && c.bm % a->W == 0) {
+        c.reuse = 1;
+    }
+#endif
+    const int unit = c.reuse ? a->KH * a->KW : 1;
+    int sps = (nsteps + c.splits - 1) / c.splits;
+    sps = (sps + unit - 1) / unit * unit;
+    c.steps_per_split = sps;
+    c.splits = (nsteps + sps - 1) / sps;      // no empty splits
     return c;
 }
 
@@ -539,6 +745,20 @@ static void launch_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const C
     }
 }
 
+#if EVC_CONV_ROWREUSE
+template <int TM, int TN>
+static void launch_reuse(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+    switch (mode) {
+        case MODE_AFFINE: hipLaunchKernelGGL((conv_rowreuse_kernel<TM, TN, MODE_AFFINE>), grid, dim3(256), lds, st, k); break;
+        case MODE_AFFINE_SILU: hipLaunchKernelGGL((conv_rowreuse_kernel<TM, TN, MODE_AFFINE_SILU>), grid, dim3(256), lds, st, k); break;
+        case MODE_SILU: hipLaunchKernelGGL((conv_rowreuse_kernel<TM, TN, MODE_SILU>), grid, dim3(256), lds, st, k); break;
+        case MODE_RELU: hipLaunchKernelGGL((conv_rowreuse_kernel<TM, TN, MODE_RELU>), grid, dim3(256), lds, st, k); break;
+        default: hipLaunchKernelGGL((conv_rowreuse_kernel<TM, TN, MODE_PLAIN>), grid, dim3(256), lds, st, k); break;
+    }
+}
+
+#endif
+
 extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stream) {
     int rc = conv_validate(a);
     if (rc != EVC_OK) return rc;
@@ -567,24 +787,39 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     k.nsteps = a->KH * a->KW * k.nchunk;
     const TileCfg cfg = conv_tile_cfg(a);
     k.splits = cfg.splits;
-    k.steps_per_split = (k.nsteps + k.splits - 1) / k.splits;
-    k.splits = (k.nsteps + k.steps_per_split - 1) / k.steps_per_split;   // no empty splits
+    k.steps_per_split = cfg.steps_per_split;
     k.ws = ws;
     if (k.splits > 1 && !ws) return EVC_EINVAL;
     k.stats = k.splits > 1 ? nullptr : a->stats_out;   // with split-K the combine kernel writes them
     if (a->stats_out && evc_conv_stats_splits(a) == 0) return EVC_EINVAL;
 
     dim3 grid((k.M + cfg.bm - 1) / cfg.bm, k.CoPad / cfg.bn, k.splits);
-    const size_t lds = (size_t)2 * (cfg.bm + cfg.bn) * KC * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (cfg.tm == 2) {
-        if (cfg.tn == 3) launch_mode<2, 3>(mode, grid, lds, st, k);
-        else if (cfg.tn == 2) launch_mode<2, 2>(mode, grid, lds, st, k);
-        else launch_mode<2, 1>(mode, grid, lds, st, k);
-    } else {
-        if (cfg.tn == 3) launch_mode<1, 3>(mode, grid, lds, st, k);
-        else if (cfg.tn == 2) launch_mode<1, 2>(mode, grid, lds, st, k);
-        else launch_mode<1, 1>(mode, grid, lds, st, k);
+#if EVC_CONV_ROWREUSE
+    if (cfg.reuse) {
+        const size_t lds = (size_t)2 * (a->KH * (cfg.bm + 2 * (a->KW / 2)) + cfg.bn) * KC * sizeof(float);
+        if (cfg.tm == 2) {
+            if (cfg.tn == 3) launch_reuse<2, 3>(mode, grid, lds, st, k);
+            else if (cfg.tn == 2) launch_reuse<2, 2>(mode, grid, lds, st, k);
+            else launch_reuse<2, 1>(mode, grid, lds, st, k);
+        } else {
+            if (cfg.tn == 3) launch_reuse<1, 3>(mode, grid, lds, st, k);
+            else if (cfg.tn == 2) launch_reuse<1, 2>(mode, grid, lds, st, k);
+            else launch_reuse<1, 1>(mode, grid, lds, st, k);
+        }
+    } else
+#endif
+    {
+        const size_t lds = (size_t)2 * (cfg.bm + cfg.bn) * KC * sizeof(float);
+        if (cfg.tm == 2) {
+            if (cfg.tn == 3) launch_mode<2, 3>(mode, grid, lds, st, k);
+            else if (cfg.tn == 2) launch_mode<2, 2>(mode, grid, lds, st, k);
+            else launch_mode<2, 1>(mode, grid, lds, st, k);
+        } else {
+            if (cfg.tn == 3) launch_mode<1, 3>(mode, grid, lds, st, k);
+            else if (cfg.tn == 2) launch_mode<1, 2>(mode, grid, lds, st, k);
+            else launch_mode<1, 1>(mode, grid, lds, st, k);
+        }
     }
     if (hipGetLastError() != hipSuccess) return EVC_ELAUNCH;
     if (k.splits > 1) {
