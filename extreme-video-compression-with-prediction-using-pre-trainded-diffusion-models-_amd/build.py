@@ -47,6 +47,7 @@ def build(force=False, verbose=False):
     headers = [os.path.join(INCLUDE, h) for h in ("evc_hip.h", "evc_rans.h")]
     hipcc = hipcc_path()
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE]
+    flags += os.environ.get("EVC_HIPCC_FLAGS", "").split()     # e.g. -DEVC_CONV_PC=1 for A/B experiments
 
     def compile_one(src):
         s = os.path.join(CSRC, src)

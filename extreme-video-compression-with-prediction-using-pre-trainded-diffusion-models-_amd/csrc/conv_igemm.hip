@@ -37,6 +37,13 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #ifndef EVC_CONV_ABLATE
 #define EVC_CONV_ABLATE 0      // DIAGNOSTIC ONLY (wrong results): bit 0 = skip the weight DMA, bit 1 = skip the activation path
 #endif
+#ifndef EVC_CONV_PC
+#define EVC_CONV_PC 0          // 1: 128-pixel tiles run on the producer/consumer-specialised kernel (8 waves)
+#endif
+#ifndef EVC_CONV_PC_OCC
+#define EVC_CONV_PC_OCC 4      // waves per SIMD the producer/consumer kernel is register-budgeted for (2: one 8-wave
+                               // workgroup per CU; 4: two -- 128 VGPRs, spills only outside the main loops)
+#endif
 #ifndef EVC_CONV_ROWREUSE
 #define EVC_CONV_ROWREUSE 0    // 1: 3x3 convs on row-aligned tiles stage the activation once per kernel row instead of once
                                // per tap (conv_rowreuse_kernel).  Correct (full GPU suite passes with it), but measured on
@@ -372,6 +379,191 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
 
     conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
 }
+
+#if EVC_CONV_PC
+// Producer / consumer specialisation of the same tiling (128 x 64*TN tile, TM = 2).  A workgroup has 8 waves:
+// waves 0-3 are CONSUMERS (fragment reads + MFMAs only, raised priority), waves 4-7 are PRODUCERS (activation
+// gather + transform + LDS write, weight slab DMA).  Waves w and w + 4 share a SIMD, so every SIMD hosts one of
+// each: the consumer's in-order stream is the bare MFMA skeleton, the producer's VALU / memory instructions fill
+// the issue slots between MFMAs.  One barrier per K-step, double-buffered LDS as in conv_igemm_kernel.
+template <int TN, int MODE>
+__global__ __launch_bounds__(512, EVC_CONV_PC_OCC) void conv_pc_kernel(ConvK p) {
+    constexpr int TM = 2;
+    constexpr int BM = 128;
+    constexpr int BN = 64 * TN;
+    constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;                    // [2][BM][16]
+    float* const Ws = smem + 2 * BM * KC;      // [2][BN][16]
+
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int split = blockIdx.z;
+    const int s_begin = split * p.steps_per_split;
+    const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
+    const bool consumer = __builtin_amdgcn_readfirstlane(threadIdx.x) < 256;    // wave-uniform role
+
+    if (consumer) {
+        __builtin_amdgcn_s_setprio(3);
+        const int tid = threadIdx.x;
+        const int lane = tid & 63, wave = tid >> 6;
+        const int wm = wave >> 1, wn = wave & 1;
+        const int l31 = lane & 31, half = lane >> 5;
+        const int fsw = (l31 >> 2) & 3;
+        const int rd0 = 4 * ((0 + half) ^ fsw), rd1 = 4 * ((2 + half) ^ fsw);
+        const int a_rd = (wm * 64 + l31) * KC, w_rd = (wn * 32 * TN + l31) * KC;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        __syncthreads();                                   // prologue tiles are in LDS
+        for (int s = s_begin; s < s_end; ++s) {
+            const int buf = (s - s_begin) & 1;
+            const float* Ab = As + buf * BM * KC + a_rd;
+            const float* Wb = Ws + buf * BN * KC + w_rd;
+            float4 a0[TM], b0[TN], a1[TM], b1[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a0[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * KC + rd0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b0[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * KC + rd0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a1[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * KC + rd1);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b1[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * KC + rd1);
+            mfma_group<TM, TN>(acc, a0, b0);
+            mfma_group<TM, TN>(acc, a1, b1);
+            __syncthreads();
+        }
+        __builtin_amdgcn_s_setprio(0);
+        conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
+    } else {
+        const int tid = threadIdx.x - 256;                 // producer thread id 0..255
+        const int wave = tid >> 6;
+        const int k4 = tid & 3;
+        const int padH = p.KH >> 1, padW = p.KW >> 1;
+        const int Ct = p.C0 + p.C1;
+        unsigned off0[TM], off1[TM], okmask[TM];
+        int rb[TM], a_lds[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = (tid >> 2) + 64 * i;
+            const int m = m0 + row;
+            const bool valid = m < p.M;
+            const int mm = valid ? m : 0;
+            const int b = mm / p.HW;
+            const int rem = mm - b * p.HW;
+            const int y = rem / p.W;
+            const int x = rem - y * p.W;
+            rb[i] = b;
+            off0[i] = ((unsigned)mm * (unsigned)p.ld0 + 4u * k4) * 4u;
+            off1[i] = ((unsigned)mm * (unsigned)p.ld1 + 4u * k4) * 4u;
+            unsigned mask = 0;
+            for (int ty = 0; ty < p.KH; ++ty)
+                for (int tx = 0; tx < p.KW; ++tx) {
+                    const int yy = y + ty - padH, xx = x + tx - padW;
+                    mask |= ((valid && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? 1u : 0u) << (ty * p.KW + tx);
+                }
+            okmask[i] = mask;
+            a_lds[i] = row * KC + 4 * (k4 ^ ((row >> 2) & 3));
+        }
+        int c_chunk, c_ty, c_tx;
+        {
+            const int taps = p.KH * p.KW;
+            c_chunk = s_begin / taps;
+            const int tap = s_begin - c_chunk * taps;
+            c_ty = tap / p.KW;
+            c_tx = tap - c_ty * p.KW;
+        }
+        float4 areg[TM], ca[TM], cs[TM];
+        bool aok[TM];
+        auto load_coefs = [&]() {
+            if (HAS_COEF) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const size_t co = (size_t)rb[i] * Ct + c_chunk * KC + 4 * k4;
+                    ca[i] = *reinterpret_cast<const float4*>(p.coef_a + co);
+                    cs[i] = *reinterpret_cast<const float4*>(p.coef_s + co);
+                }
+            }
+        };
+        auto load_a = [&]() {                              // activation gather of the cursor's step -> registers
+            const int c = c_chunk * KC;
+            const bool first = c < p.C0;
+            const char* src = reinterpret_cast<const char*>(first ? p.src0 : p.src1);
+            const int ld = first ? p.ld0 : p.ld1;
+            const int tap = c_ty * p.KW + c_tx;
+            const int delta = (((c_ty - padH) * p.W + (c_tx - padW)) * ld + (first ? c : c - p.C0)) * 4;
+            const unsigned safe = (unsigned)((first ? c : c - p.C0) + 4 * k4) * 4u;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                aok[i] = (okmask[i] >> tap) & 1u;
+                const unsigned o = aok[i] ? (first ? off0[i] : off1[i]) + (unsigned)delta : safe;
+                areg[i] = *reinterpret_cast<const float4*>(src + o);
+            }
+        };
+        auto dma_w = [&](int buf) {                        // weight slab of the cursor's step -> LDS buffer `buf`
+            const int tap = c_ty * p.KW + c_tx;
+            const float* wt = p.w + ((size_t)(tap * p.nchunk + c_chunk) * p.CoPad + n0) * KC;
+            float* wl = Ws + buf * BN * KC;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                __builtin_amdgcn_global_load_lds((glb_void*)(wt + (size_t)(tid + 256 * j) * 4),
+                                                 (lds_void*)(wl + (wave * 16 + 64 * j) * KC), 16, 0, 0);
+        };
+        auto advance = [&]() {
+            ++c_tx;
+            if (c_tx == p.KW) { c_tx = 0; ++c_ty; }
+            if (c_ty == p.KH) { c_ty = 0; ++c_chunk; }
+        };
+        auto store_a = [&](int buf) {
+            float* A = As + buf * BM * KC;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                *reinterpret_cast<float4*>(A + a_lds[i]) = transform<MODE>(areg[i], ca[i], cs[i], aok[i]);
+        };
+        // Prologue: step s_begin fully staged; the gather of step s_begin + 1 is left in flight in registers.
+        if (s_begin < s_end) {
+            load_coefs();
+            load_a();
+            store_a(0);
+            dma_w(0);
+            if (s_begin + 1 < s_end) {
+                const int prev_chunk = c_chunk;
+                advance();
+                if (HAS_COEF && c_chunk != prev_chunk) load_coefs();
+                load_a();
+            }
+        }
+        __syncthreads();     // drains everything once (prologue only)
+        if (s_begin + 1 < s_end) load_a();   // re-issue: the barrier above waited for the first copy
+        for (int s = s_begin; s < s_end; ++s) {
+            const int buf = (s - s_begin) & 1;
+            bool reloaded = false;
+            if (s + 1 < s_end) {
+                store_a(buf ^ 1);              // registers hold step s+1 (issued a whole step ago)
+                dma_w(buf ^ 1);                // weights of step s+1 (cursor points at s+1)
+                if (s + 2 < s_end) {
+                    const int prev_chunk = c_chunk;
+                    advance();
+                    if (HAS_COEF && c_chunk != prev_chunk) { load_coefs(); reloaded = true; }
+                    load_a();                  // step s+2 stays in flight across the barrier
+                }
+            }
+            // Wait for the LDS writes and the weight DMA (older), NOT for the gathers issued after it.
+            if (s + 2 < s_end) {
+                if (reloaded) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * TM) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(TM) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+}
+#endif  // EVC_CONV_PC
 
 #if EVC_CONV_ROWREUSE
 // Row-reuse variant: same GEMM tiling, but the activation operand of one channel chunk is staged ONCE per kernel
@@ -745,6 +937,19 @@ static void launch_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const C
     }
 }
 
+#if EVC_CONV_PC
+template <int TN>
+static void launch_pc(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+    switch (mode) {
+        case MODE_AFFINE: hipLaunchKernelGGL((conv_pc_kernel<TN, MODE_AFFINE>), grid, dim3(512), lds, st, k); break;
+        case MODE_AFFINE_SILU: hipLaunchKernelGGL((conv_pc_kernel<TN, MODE_AFFINE_SILU>), grid, dim3(512), lds, st, k); break;
+        case MODE_SILU: hipLaunchKernelGGL((conv_pc_kernel<TN, MODE_SILU>), grid, dim3(512), lds, st, k); break;
+        case MODE_RELU: hipLaunchKernelGGL((conv_pc_kernel<TN, MODE_RELU>), grid, dim3(512), lds, st, k); break;
+        default: hipLaunchKernelGGL((conv_pc_kernel<TN, MODE_PLAIN>), grid, dim3(512), lds, st, k); break;
+    }
+}
+#endif
+
 #if EVC_CONV_ROWREUSE
 template <int TM, int TN>
 static void launch_reuse(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
@@ -795,6 +1000,14 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
 
     dim3 grid((k.M + cfg.bm - 1) / cfg.bm, k.CoPad / cfg.bn, k.splits);
     hipStream_t st = (hipStream_t)stream;
+#if EVC_CONV_PC
+    if (cfg.tm == 2) {
+        const size_t lds = (size_t)2 * (cfg.bm + cfg.bn) * KC * sizeof(float);
+        if (cfg.tn == 3) launch_pc<3>(mode, grid, lds, st, k);
+        else if (cfg.tn == 2) launch_pc<2>(mode, grid, lds, st, k);
+        else launch_pc<1>(mode, grid, lds, st, k);
+    } else
+#endif
 #if EVC_CONV_ROWREUSE
     if (cfg.reuse) {
         const size_t lds = (size_t)2 * (a->KH * (cfg.bm + 2 * (a->KW / 2)) + cfg.bn) * KC * sizeof(float);
