@@ -53,6 +53,9 @@ def build_parser():
     p.add_argument("--batch", type=int, default=8,
                    help="mask policy: clips decoded together per GPU (the reference runs one clip at a time)")
     p.add_argument("--groups", type=int, default=2, help="concurrent clip groups (HIP streams) inside a batch")
+    p.add_argument("--bitstream-dir", type=str, default=None,
+                   help="mask policy: write each batch's key-frame strings + mask as an EVC1 container here and "
+                        "decode from the bytes read back (container.py)")
     return p
 
 
@@ -164,7 +167,16 @@ def main(argv=None):
                     xk = torch.nn.functional.pad(gt[:, f], (0, pad[0], 0, pad[1]))
                     enc = model.compress(xk.to(device))
                     keys.append(enc["strings"]); shape = enc["shape"]
-                frames = dec.decode(mask, keys, shape, generator=gen)[..., :gt.shape[-2], :gt.shape[-1]]
+                d_rx, keys_rx, shape_rx = mask, keys, shape
+                if args.bitstream_dir:                             # sender -> file -> receiver
+                    from . import container
+                    os.makedirs(args.bitstream_dir, exist_ok=True)
+                    path = os.path.join(args.bitstream_dir, f"clips_{chunk[0]}_{chunk[-1]}_q{q}.evc")
+                    with open(path, "wb") as fh:
+                        fh.write(container.pack(mask, keys, shape))
+                    with open(path, "rb") as fh:
+                        d_rx, keys_rx, shape_rx = container.unpack(fh.read())
+                frames = dec.decode(d_rx, keys_rx, shape_rx, generator=gen)[..., :gt.shape[-2], :gt.shape[-1]]
                 x_all = frames.cpu().numpy()
                 for j, vid in enumerate(chunk):
                     bits = [count_bits([[[[p[j]] for p in sl] for sl in k[0]], [k[1][j]]]) for k in keys]

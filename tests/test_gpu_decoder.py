@@ -96,3 +96,27 @@ def test_generation_is_invariant_to_concurrent_clip_grouping():
     dec = ClipDecoder(net, None, cfg, S.get_sampler("DDPM"), groups=2)
     out = dec.generate(cond, generator=torch.Generator(device="cuda").manual_seed(3))
     assert out.shape == (5, 5, 3, 32, 32) and bool(torch.isfinite(out).all())
+
+
+def test_full_ddpm_chunk_psnr_against_oracle():
+    """One whole chunk with the reference's schedule (1000 steps subsampled to 100 + the denoise call = 101 network
+    evaluations, clip to [-1, 1] every step) on a reduced network: decoded [0,1] frames of the HIP path vs the CPU
+    oracle with the same injected noise.  Tolerance of SURVEY.md 8c: PSNR >= 60 dB."""
+    import evc_amd  # noqa: F401
+    from evc_amd import sampler as S
+    from evc_amd.config import default_config
+    from evc_amd.scorenet import ScoreNet
+    from oracle import samplers as OS, schedule as OSch, scorenet as ON
+    cfg = default_config(32, 32, 32, subsample=100)
+    d = ON.Dims(ngf=32, n_head_channels=32, image_size=32)
+    p = ON.seeded_params(d, 33)
+    net = ScoreNet(cfg, p)
+    x_T, cond = rnd(34, 1, 15, 32, 32), rnd(35, 1, 6, 32, 32).clamp(-1, 1)
+    noises = [rnd(2000 + i, 1, 15, 32, 32) for i in range(100)]
+    out = S.ddpm_sampler(x_T.cuda(), net, cond=cond.cuda(), subsample_steps=100, denoise=True, clip_before=True,
+                         final_only=True, noise_fn=lambda i, x: noises[i])[0].cpu()
+    ref = OS.ddpm(x_T.clone(), lambda x, t: ON.forward(p, d, x, t, cond=cond), OSch.base_schedule(),
+                  subsample_steps=100, noise_fn=lambda i, x: noises[i])[0]
+    a, b = ((out + 1) / 2).clamp(0, 1).double(), ((ref + 1) / 2).clamp(0, 1).double()
+    psnr = 10 * torch.log10(1.0 / ((a - b) ** 2).mean())
+    assert float(psnr) >= 60.0, float(psnr)

@@ -93,3 +93,20 @@ def test_conv_dispatch_queries_without_gpu():
     assert q(1, 8, 24, 32, 192, 3, 3, splits=1) == 6               # 192 pixels = 3 tiles of 64 -> six 32-pixel runs
     assert q(1, 8, 20, 32, 192, 3, 3, splits=1) == 0               # H*W not a multiple of 64
     assert q(1, 128, 128, 24, 192, 3, 3) == 0                      # invalid (channels % 16) -> never fused
+
+
+def test_container_roundtrip_and_corruption():
+    from evc_amd import container
+    rng = np.random.default_rng(0)
+    d = np.zeros(30, dtype=np.int64)
+    d[[0, 1, 12]] = 1
+    B = 3
+    mk = lambda: bytes(rng.integers(0, 256, int(rng.integers(8, 60)), dtype=np.uint8))
+    keys = [[[[[mk() for _ in range(B)] for _ in range(2)] for _ in range(5)], [mk() for _ in range(B)]] for _ in range(3)]
+    blob = container.pack(d, keys, (2, 2))
+    d2, keys2, shape = container.unpack(blob)
+    assert shape == (2, 2) and (d2 == d).all() and keys2 == keys
+    assert container.payload_bits(keys2) == 8 * (len(blob) - 14 - 30 - 4 * 3 * B * 11)
+    for bad in (blob[:-3], b"XXXX" + blob[4:], blob + b"\0"):
+        with pytest.raises(ValueError):
+            container.unpack(bad)
