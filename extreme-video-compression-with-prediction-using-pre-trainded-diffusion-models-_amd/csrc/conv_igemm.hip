@@ -380,6 +380,199 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 on the bf16 matrix cores ("bf16x6").  gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the rate of the f32
+// MFMA.  Every fp32 value is EXACTLY the sum of three bf16 values (8 + 8 + 8 significand bits):
+//     x = x1 + x2 + x3,   x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2),
+// bf16 x bf16 products are exact in fp32 and the MFMA accumulates in fp32, so
+//     x*y = x1y1 + (x1y2 + x2y1) + (x1y3 + x2y2 + x3y1) + O(2^-24 |xy|)
+// costs 6 bf16 MFMAs per 16-deep K slice (192 cycles) instead of 8 f32 MFMAs (512 cycles).  The three dropped
+// terms are below one fp32 rounding of the product.  Measured on MI355X against an fp64 reference
+// (tools/split_numerics.hip, K = 1728 ... 13824): max / rms error of this scheme is equal to or slightly BELOW
+// that of the v_mfma_f32_32x32x2_f32 chain (e.g. K = 3456: 1.5e-6 / 2.1e-7 vs 1.9e-6 / 2.4e-7 of max|C|), and
+// identical to the 9-product version.  So this is an fp32 convolution, not a reduced-precision one.
+//
+// Same tiling, gather, transform and epilogue as conv_igemm_kernel.  Differences: the K-step (16 channels) is ONE
+// MFMA k-depth; LDS rows are 32 bytes (16 bf16) in three planes per operand, the 16-byte half of a row XOR-ed with
+// (row >> 3) & 1 (conflict-free for the ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31});
+// a thread stages 8 channels of one pixel (2 float4 loads -> transform -> split -> 3 ds_write_b128); the weights
+// are split at pack time and arrive by LDS-DMA.  LDS = 192 * (BM + BN) bytes (60 KB at 128 x 192).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3_bf16(const float4& v0, const float4& v1, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 a = (__bf16)x[j];
+        const float r = x[j] - (float)a;
+        const __bf16 b = (__bf16)r;
+        p1[j] = a; p2[j] = b; p3[j] = (__bf16)(r - (float)b);
+    }
+}
+
+template <int TM, int TN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
+    constexpr int BM = 64 * TM;
+    constexpr int BN = 64 * TN;
+    constexpr int RB = 32;                       // bytes per LDS row: 16 bf16
+    constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    char* const As = smem_b;                          // [2][3][BM][32 B]
+    char* const Ws = smem_b + 2 * 3 * BM * RB;        // [2][3][BN][32 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int split = blockIdx.z;
+    const int s_begin = split * p.steps_per_split;
+    const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
+
+    // ---- per-thread gather state: pixel row tid/2, channel half kh (8 channels) ----
+    const int row = tid >> 1, kh = tid & 1;
+    const bool a_active = TM == 2 || row < BM;                        // wave-uniform (TM = 1: waves 0, 1)
+    const int padH = p.KH >> 1, padW = p.KW >> 1;
+    const int Ct = p.C0 + p.C1;
+    unsigned off0, off1, okmask = 0;
+    int rb;
+    {
+        const int m = m0 + row;
+        const bool valid = a_active && m < p.M;
+        const int mm = valid ? m : 0;
+        const int b = mm / p.HW;
+        const int rem = mm - b * p.HW;
+        const int y = rem / p.W;
+        const int x = rem - y * p.W;
+        rb = b;
+        off0 = ((unsigned)mm * (unsigned)p.ld0 + 8u * kh) * 4u;
+        off1 = ((unsigned)mm * (unsigned)p.ld1 + 8u * kh) * 4u;
+        for (int ty = 0; ty < p.KH; ++ty)
+            for (int tx = 0; tx < p.KW; ++tx) {
+                const int yy = y + ty - padH, xx = x + tx - padW;
+                const bool ok = valid && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                okmask |= (ok ? 1u : 0u) << (ty * p.KW + tx);
+            }
+    }
+    const int a_lds = row * RB + 16 * (kh ^ ((row >> 3) & 1));        // byte offset inside one plane
+    // fragment reads: lane (r = l31, h = half) takes k = 8h .. 8h+7 of row r; tile / wave row offsets are
+    // multiples of 32 rows, so the XOR term depends on the lane only
+    const int fr = l31 * RB + 16 * (half ^ ((l31 >> 3) & 1));
+    const int a_rd = wm * 32 * TM * RB + fr, w_rd = wn * 32 * TN * RB + fr;
+
+    int c_chunk, c_ty, c_tx;
+    {
+        const int taps = p.KH * p.KW;
+        c_chunk = s_begin / taps;
+        const int tap = s_begin - c_chunk * taps;
+        c_ty = tap / p.KW;
+        c_tx = tap - c_ty * p.KW;
+    }
+    float4 areg[2], ca[2], cs[2];
+    bool aok = false;
+
+    auto load_coefs = [&]() {
+        if (HAS_COEF) {
+            const size_t co = (size_t)rb * Ct + c_chunk * KC + 8 * kh;
+            ca[0] = *reinterpret_cast<const float4*>(p.coef_a + co);
+            ca[1] = *reinterpret_cast<const float4*>(p.coef_a + co + 4);
+            cs[0] = *reinterpret_cast<const float4*>(p.coef_s + co);
+            cs[1] = *reinterpret_cast<const float4*>(p.coef_s + co + 4);
+        }
+    };
+    auto issue_loads = [&](int buf) {
+        const int c = c_chunk * KC;
+        const bool first = c < p.C0;                              // wave-uniform
+        const char* src = reinterpret_cast<const char*>(first ? p.src0 : p.src1);
+        const int ld = first ? p.ld0 : p.ld1;
+        const int tap = c_ty * p.KW + c_tx;
+        const int delta = (((c_ty - padH) * p.W + (c_tx - padW)) * ld + (first ? c : c - p.C0)) * 4;
+        const unsigned safe = (unsigned)((first ? c : c - p.C0) + 8 * kh) * 4u;   // pixel 0: always legal
+        if (a_active && !(EVC_CONV_ABLATE & 2)) {
+            aok = (okmask >> tap) & 1u;
+            const unsigned o = aok ? (first ? off0 : off1) + (unsigned)delta : safe;
+            areg[0] = *reinterpret_cast<const float4*>(src + o);
+            areg[1] = *reinterpret_cast<const float4*>(src + o + 16);
+        }
+        // W slab: 3 planes x BN rows x 32 B = 6*TN KiB; one wave instruction moves 1 KiB (32 rows of one plane)
+        const char* wt = reinterpret_cast<const char*>(p.w) + (size_t)(tap * p.nchunk + c_chunk) * 3 * p.CoPad * RB;
+        char* wl = Ws + buf * 3 * BN * RB;
+        // (6*TN pieces over 4 waves: when that does not divide, the last round's surplus waves repeat the final
+        // piece -- identical bytes to the same place -- which keeps the K-step free of branches)
+#pragma unroll
+        for (int j = 0; j < ((EVC_CONV_ABLATE & 1) ? 0 : (6 * TN + 3) / 4); ++j) {
+            const int idx = min(wave + 4 * j, 6 * TN - 1);         // wave-uniform
+            const int part = idx / (2 * TN), seg = idx - part * (2 * TN);
+            __builtin_amdgcn_global_load_lds((glb_void*)(wt + ((size_t)part * p.CoPad + n0 + seg * 32) * RB + lane * 16),
+                                             (lds_void*)(wl + (part * BN + seg * 32) * RB), 16, 0, 0);
+        }
+    };
+    auto advance = [&]() {
+        ++c_tx;
+        if (c_tx == p.KW) { c_tx = 0; ++c_ty; }
+        if (c_ty == p.KH) { c_ty = 0; ++c_chunk; }
+    };
+    auto store_a = [&](int buf) {
+        if (!a_active || (EVC_CONV_ABLATE & 2)) return;
+        bf16x8 p1, p2, p3;
+        split3_bf16(transform<MODE>(areg[0], ca[0], cs[0], aok), transform<MODE>(areg[1], ca[1], cs[1], aok), p1, p2, p3);
+        char* A = As + buf * 3 * BM * RB + a_lds;
+        *reinterpret_cast<bf16x8*>(A) = p1;
+        *reinterpret_cast<bf16x8*>(A + BM * RB) = p2;
+        *reinterpret_cast<bf16x8*>(A + 2 * BM * RB) = p3;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (s_begin < s_end) {
+        load_coefs();
+        issue_loads(0);
+        store_a(0);
+    }
+    __syncthreads();
+
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) {
+            const int prev_chunk = c_chunk;
+            advance();
+            if (HAS_COEF && c_chunk != prev_chunk) load_coefs();
+        }
+        issue_loads(buf ^ 1);
+
+        const char* Ab = As + buf * 3 * BM * RB + a_rd;
+        const char* Wb = Ws + buf * 3 * BN * RB + w_rd;
+        bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i][q] = *reinterpret_cast<const bf16x8*>(Ab + (q * BM + i * 32) * RB);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j][q] = *reinterpret_cast<const bf16x8*>(Wb + (q * BN + j * 32) * RB);
+        }
+#define EVC_SPLIT_TERM(qa, qb)                                                                          \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)  \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
+        EVC_SPLIT_TERM(2, 0) EVC_SPLIT_TERM(1, 1) EVC_SPLIT_TERM(0, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        store_a(buf ^ 1);
+        EVC_SPLIT_TERM(1, 0) EVC_SPLIT_TERM(0, 1) EVC_SPLIT_TERM(0, 0)
+#undef EVC_SPLIT_TERM
+        __syncthreads();
+    }
+
+    conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
+}
+
 #if EVC_CONV_PC
 // Producer / consumer specialisation of the same tiling (128 x 64*TN tile, TM = 2).  A workgroup has 8 waves:
 // waves 0-3 are CONSUMERS (fragment reads + MFMAs only, raised priority), waves 4-7 are PRODUCERS (activation
@@ -818,6 +1011,31 @@ __global__ void conv_pack_weights_kernel(const float* w, float* packed, int Co, 
     }
 }
 
+// bf16x6 weights: w [Co][Ci][KH][KW] -> [KH*KW][Ci/16][3 planes][CoPad][16 bf16], 16-byte halves swizzled like the
+// LDS image (half ^ ((co >> 3) & 1)) so the linear LDS-DMA copy lands conflict-free.
+__global__ void conv_pack_split_kernel(const float* w, __bf16* packed, int Co, int CoPad, int Ci, int KH, int KW) {
+    const int taps = KH * KW, nchunk = Ci / KC;
+    const size_t total = (size_t)taps * nchunk * CoPad * KC;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % KC);
+        size_t t = i / KC;
+        const int co = (int)(t % CoPad); t /= CoPad;
+        const int chunk = (int)(t % nchunk);
+        const int tap = (int)(t / nchunk);
+        float v = 0.f;
+        if (co < Co) v = w[((size_t)co * Ci + chunk * KC + k) * taps + tap];
+        const __bf16 a = (__bf16)v;
+        const float r = v - (float)a;
+        const __bf16 b = (__bf16)r;
+        const __bf16 c = (__bf16)(r - (float)b);
+        const int pos = (((k >> 3) ^ ((co >> 3) & 1)) << 3) | (k & 7);
+        const size_t base = (size_t)(tap * nchunk + chunk) * 3 * CoPad * KC;
+        packed[base + ((size_t)0 * CoPad + co) * KC + pos] = a;
+        packed[base + ((size_t)1 * CoPad + co) * KC + pos] = b;
+        packed[base + ((size_t)2 * CoPad + co) * KC + pos] = c;
+    }
+}
+
 int pick_tn(int CoPad) {
     if (CoPad % 192 == 0) return 3;
     if (CoPad % 128 == 0) return 2;
@@ -841,6 +1059,24 @@ extern "C" int evc_conv_pack_weights_f32(const float* w, float* packed, int Co, 
     return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
 }
 
+extern "C" long long evc_conv_packed_bytes(int Co, int Ci, int KH, int KW, int arith) {
+    if (arith != EVC_ARITH_F32 && arith != EVC_ARITH_BF16X6) return EVC_EINVAL;
+    const long long elems = evc_conv_packed_floats(Co, Ci, KH, KW);
+    return arith == EVC_ARITH_BF16X6 ? elems * 6 : elems * 4;     // three bf16 planes vs one f32
+}
+
+extern "C" int evc_conv_pack_weights(const float* w, void* packed, int Co, int Ci, int KH, int KW, int arith,
+                                     void* stream) {
+    if (arith == EVC_ARITH_F32) return evc_conv_pack_weights_f32(w, (float*)packed, Co, Ci, KH, KW, stream);
+    if (arith != EVC_ARITH_BF16X6) return EVC_EINVAL;
+    if (!w || !packed || Co <= 0 || Ci <= 0 || Ci % KC != 0 || KH <= 0 || KW <= 0) return EVC_EINVAL;
+    const long long total = evc_conv_packed_floats(Co, Ci, KH, KW);
+    int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(conv_pack_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)packed, Co,
+                       evc_conv_co_pad(Co), Ci, KH, KW);
+    return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
+}
+
 static int conv_validate(const evc_conv_args* a) {
     if (!a || !a->src0 || !a->w_packed || !a->out) return EVC_EINVAL;
     if (a->C0 <= 0 || a->C0 % KC != 0 || a->C1 < 0 || a->C1 % KC != 0) return EVC_EINVAL;
@@ -852,6 +1088,7 @@ static int conv_validate(const evc_conv_args* a) {
     if (a->KH <= 0 || a->KW <= 0 || !(a->KH & 1) || !(a->KW & 1)) return EVC_EINVAL;
     if (a->ld_out < a->Co || (a->res && a->ld_res < a->Co)) return EVC_EINVAL;
     if ((long long)a->B * a->H * a->W > 0x7fffffffLL) return EVC_EINVAL;
+    if (a->arith != EVC_ARITH_F32 && a->arith != EVC_ARITH_BF16X6) return EVC_EINVAL;
     return EVC_OK;
 }
 
@@ -937,6 +1174,17 @@ static void launch_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const C
     }
 }
 
+template <int TM, int TN>
+static void launch_split(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+    switch (mode) {
+        case MODE_AFFINE: hipLaunchKernelGGL((conv_split_kernel<TM, TN, MODE_AFFINE>), grid, dim3(256), lds, st, k); break;
+        case MODE_AFFINE_SILU: hipLaunchKernelGGL((conv_split_kernel<TM, TN, MODE_AFFINE_SILU>), grid, dim3(256), lds, st, k); break;
+        case MODE_SILU: hipLaunchKernelGGL((conv_split_kernel<TM, TN, MODE_SILU>), grid, dim3(256), lds, st, k); break;
+        case MODE_RELU: hipLaunchKernelGGL((conv_split_kernel<TM, TN, MODE_RELU>), grid, dim3(256), lds, st, k); break;
+        default: hipLaunchKernelGGL((conv_split_kernel<TM, TN, MODE_PLAIN>), grid, dim3(256), lds, st, k); break;
+    }
+}
+
 #if EVC_CONV_PC
 template <int TN>
 static void launch_pc(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
@@ -1000,6 +1248,18 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
 
     dim3 grid((k.M + cfg.bm - 1) / cfg.bm, k.CoPad / cfg.bn, k.splits);
     hipStream_t st = (hipStream_t)stream;
+    if (a->arith == EVC_ARITH_BF16X6) {
+        const size_t lds = (size_t)2 * 3 * (cfg.bm + cfg.bn) * 32;
+        if (cfg.tm == 2) {
+            if (cfg.tn == 3) launch_split<2, 3>(mode, grid, lds, st, k);
+            else if (cfg.tn == 2) launch_split<2, 2>(mode, grid, lds, st, k);
+            else launch_split<2, 1>(mode, grid, lds, st, k);
+        } else {
+            if (cfg.tn == 3) launch_split<1, 3>(mode, grid, lds, st, k);
+            else if (cfg.tn == 2) launch_split<1, 2>(mode, grid, lds, st, k);
+            else launch_split<1, 1>(mode, grid, lds, st, k);
+        }
+    } else
 #if EVC_CONV_PC
     if (cfg.tm == 2) {
         const size_t lds = (size_t)2 * (cfg.bm + cfg.bn) * KC * sizeof(float);

@@ -16,6 +16,19 @@ HIP_SO = os.path.join(HERE, "lib", "libevc_hip.so")
 RANS_SO = os.path.join(HERE, "lib", "libevc_rans.so")
 
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
+# How the convolution multiplies (include/evc_hip.h EVC_ARITH_*).  Both are fp32 convolutions with fp32 accumulation;
+# BF16X6 splits every fp32 operand exactly into three bf16 values and runs the six significant cross products on the
+# bf16 matrix cores (measured error vs fp64: equal to or below the f32 MFMA chain).  The packed weights carry the
+# choice in their dtype (float32 / bfloat16).  EVC_CONV_ARITH=f32|bf16x6 overrides the default.
+ARITH_F32, ARITH_BF16X6 = 0, 1
+_ARITH_NAMES = {"f32": ARITH_F32, "bf16x6": ARITH_BF16X6}
+
+
+def default_arith():
+    name = os.environ.get("EVC_CONV_ARITH", "bf16x6").lower()
+    if name not in _ARITH_NAMES:
+        raise ValueError(f"EVC_CONV_ARITH must be one of {sorted(_ARITH_NAMES)}, got {name!r}")
+    return _ARITH_NAMES[name]
 
 
 class EvcLibraryError(RuntimeError):
@@ -35,7 +48,7 @@ class ConvArgs(ctypes.Structure):
                 ("out_scale", c_float), ("act_out", c_int),
                 ("out", c_void_p), ("ld_out", c_int),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("Co", c_int), ("KH", c_int), ("KW", c_int),
-                ("splits", c_int), ("stats_out", c_void_p)]
+                ("splits", c_int), ("stats_out", c_void_p), ("arith", c_int)]
 
 
 # name -> (restype, argtypes); exactly the symbols declared in include/evc_hip.h
@@ -58,6 +71,8 @@ HIP_SYMBOLS = {
     "evc_conv_co_pad": (c_int, [c_int]),
     "evc_conv_packed_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
     "evc_conv_pack_weights_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "evc_conv_packed_bytes": (c_longlong, [c_int, c_int, c_int, c_int, c_int]),
+    "evc_conv_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "evc_conv_choose_splits": (c_int, [POINTER(ConvArgs)]),
     "evc_conv_stats_splits": (c_int, [POINTER(ConvArgs)]),
     "evc_conv_workspace_bytes": (c_longlong, [POINTER(ConvArgs)]),
@@ -263,16 +278,26 @@ def affine_act(x, coef, act, out=None, coef_col=0):
     return out.t if isinstance(out, Cols) else out
 
 
-def conv_pack_weights(w):
-    """w: (Co, Ci, KH, KW) device float32 with Ci % 16 == 0 -> packed flat tensor."""
+def conv_pack_weights(w, arith=None):
+    """w: (Co, Ci, KH, KW) device float32 with Ci % 16 == 0 -> packed flat tensor: float32 for ARITH_F32, bfloat16
+    (three planes) for ARITH_BF16X6; ``conv2d_nhwc`` picks the kernel from that dtype."""
     L = hip_lib()
+    arith = default_arith() if arith is None else arith
     w = w.contiguous()
     Co, Ci, KH, KW = w.shape
-    n = L.evc_conv_packed_floats(Co, Ci, KH, KW)
-    packed = torch.empty((n,), device=w.device, dtype=torch.float32)
-    _check(L.evc_conv_pack_weights_f32(fptr(w), fptr(packed), Co, Ci, KH, KW, stream_ptr()),
-           "evc_conv_pack_weights_f32")
+    nbytes = L.evc_conv_packed_bytes(Co, Ci, KH, KW, arith)
+    if nbytes < 0:
+        raise EvcKernelError(f"evc_conv_packed_bytes rejected the arguments ({nbytes})")
+    if arith == ARITH_BF16X6:
+        packed = torch.empty((nbytes // 2,), device=w.device, dtype=torch.bfloat16)
+    else:
+        packed = torch.empty((nbytes // 4,), device=w.device, dtype=torch.float32)
+    _check(L.evc_conv_pack_weights(fptr(w), ptr(packed), Co, Ci, KH, KW, arith, stream_ptr()), "evc_conv_pack_weights")
     return packed
+
+
+def packed_arith(w_packed):
+    return ARITH_BF16X6 if w_packed.dtype == torch.bfloat16 else ARITH_F32
 
 
 _ws_cache = {}
@@ -339,7 +364,7 @@ def conv2d_nhwc(src0, w_packed, Co, KH, KW, bias=None, src1=None, coef=None, act
     ca, cs = coef if coef is not None else (None, None)
     a = ConvArgs(p0, p1, C0, C1, ld0, ld1, ptr(ca), ptr(cs), act_in, ptr(w_packed), ptr(bias), ptr(res),
                  0 if res is None else res.shape[-1], float(out_scale), act_out, po, ldo,
-                 B, H, W, Co, KH, KW, splits, None)
+                 B, H, W, Co, KH, KW, splits, None, packed_arith(w_packed))
     stats = None
     if want_stats:
         ns = L.evc_conv_stats_splits(ctypes.byref(a))
@@ -357,7 +382,7 @@ def conv2d_nhwc(src0, w_packed, Co, KH, KW, bias=None, src1=None, coef=None, act
     _check(L.evc_conv2d_nhwc_f32(ctypes.byref(a), ptr(ws), stream_ptr()), "evc_conv2d_nhwc_f32")
     if CONV_PROFILE is not None:
         e1.record(st)
-        CONV_PROFILE.append(dict(variant=conv_variant(Co), split=nbytes > 0, e0=e0, e1=e1,
+        CONV_PROFILE.append(dict(variant=conv_variant(Co), split=nbytes > 0, e0=e0, e1=e1, arith=a.arith,
                                  flops=2.0 * B * H * W * Co * KH * KW * (C0 + C1),
                                  shape=(B, H, W, C0 + C1, Co, KH)))
     result = out.t if isinstance(out, Cols) else out
@@ -371,7 +396,7 @@ def conv_fused_stats_splits(B, H, W, Ci, Co, KH, KW, splits=0):
     0 when it falls back to a separate ``evc_chan_stats_f32`` pass (C query, no launch)."""
     d = c_void_p(16)   # any non-null pointers: the query validates shapes only
     a = ConvArgs(d, None, Ci, 0, 0, 0, None, None, ACT_NONE, d, None, None, 0, 1.0, ACT_NONE, d, Co, B, H, W, Co, KH,
-                 KW, splits, None)
+                 KW, splits, None, ARITH_F32)
     return hip_lib(require_device=False).evc_conv_stats_splits(ctypes.byref(a))
 
 

@@ -24,6 +24,15 @@ extern "C" {
 #define EVC_ACT_SILU 1
 #define EVC_ACT_RELU 2
 
+/* How the convolution multiplies (both are fp32 convolutions with fp32 accumulation):
+ *   EVC_ARITH_F32     v_mfma_f32_32x32x2_f32: exact fp32 products, k-ordered fmaf chain;
+ *   EVC_ARITH_BF16X6  every fp32 operand is split EXACTLY into three bf16 values and the six significant cross
+ *                     products run on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA rate); the dropped terms are below
+ *                     one fp32 rounding of a product.  Measured error against fp64 on MI355X: equal to or below
+ *                     that of EVC_ARITH_F32 (tools/split_numerics.hip). */
+#define EVC_ARITH_F32 0
+#define EVC_ARITH_BF16X6 1
+
 /* Library / device identification. evc_arch() returns the gfx target the code object was built
  * for ("gfx950"). evc_device_ok() returns 1 when the current HIP device can run it. */
 const char* evc_version(void);
@@ -99,11 +108,16 @@ typedef struct {
     float* stats_out;      /* optional: per-channel moments of `out`, fused into the epilogue, in the layout of
                               evc_chan_stats_f32 with nsplit = evc_conv_stats_splits() ([B][nsplit][Co][2] = {sum, sumsq}
                               of each pixel run). Only honoured when that is > 0; else must be NULL. */
+    int arith;             /* EVC_ARITH_*: must match the packing of w_packed */
 } evc_conv_args;
 int evc_conv_co_pad(int Co);
 long long evc_conv_packed_floats(int Co, int Ci, int KH, int KW);
 /* w: [Co][Ci][KH][KW] (PyTorch Conv2d layout, device) -> packed (device). */
 int evc_conv_pack_weights_f32(const float* w, float* packed, int Co, int Ci, int KH, int KW, void* stream);
+/* The same for either arithmetic: EVC_ARITH_F32 -> the layout above (4 bytes per element), EVC_ARITH_BF16X6 ->
+ * [KH*KW][Ci/16][3 planes][CoPad][16 bf16] (6 bytes per element). */
+long long evc_conv_packed_bytes(int Co, int Ci, int KH, int KW, int arith);
+int evc_conv_pack_weights(const float* w, void* packed, int Co, int Ci, int KH, int KW, int arith, void* stream);
 int evc_conv_choose_splits(const evc_conv_args* a);
 /* The number of pixel runs per image (H*W/64 or H*W/32) for which the fused moments will be written, when they are
  * available for these arguments (H*W % 64 == 0 and either split-K -- the combine kernel writes them -- or only full

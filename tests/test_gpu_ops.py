@@ -19,6 +19,12 @@ def L():
     return lib
 
 
+@pytest.fixture(params=[0, 1], ids=["f32mfma", "bf16x6"])
+def arith(request):
+    """Both multiplication schemes of the convolution (include/evc_hip.h EVC_ARITH_*), same tolerances."""
+    return request.param
+
+
 def rel(a, b):
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
@@ -38,18 +44,18 @@ def silu_affine(x, a, s):
 
 @pytest.mark.parametrize("B,H,W,Ci,Co,K", [(2, 16, 16, 192, 192, 3), (1, 5, 7, 32, 48, 3), (2, 8, 8, 64, 15, 3),
                                             (3, 8, 8, 96, 128, 1), (1, 9, 6, 32, 64, 5), (1, 1, 7, 192, 768, 1)])
-def test_conv_plain(L, B, H, W, Ci, Co, K):
+def test_conv_plain(L, arith, B, H, W, Ci, Co, K):
     x = rnd(1, B, Ci, H, W).cuda()
     w = (rnd(2, Co, Ci, K, K) / np.sqrt(Ci * K * K)).cuda()
     b = rnd(3, Co).cuda()
     ref = F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=K // 2)
-    out = L.conv2d_nhwc(nhwc(x), L.conv_pack_weights(w), Co, K, K, bias=b)
+    out = L.conv2d_nhwc(nhwc(x), L.conv_pack_weights(w, arith), Co, K, K, bias=b)
     assert out.shape == (B, H, W, Co)
     assert rel(nchw(out), ref) < 1e-5
 
 
 @pytest.mark.parametrize("splits", [0, 1, 3, 7])
-def test_conv_fused_everything(L, splits):
+def test_conv_fused_everything(L, arith, splits):
     """two-source concat + GroupNorm affine + SiLU on load + bias + residual + rescale (+ split-K)."""
     B, H, W, C0, C1, Co = 2, 8, 8, 96, 64, 192
     x0, x1 = rnd(4, B, C0, H, W).cuda(), rnd(5, B, C1, H, W).cuda()
@@ -58,41 +64,41 @@ def test_conv_fused_everything(L, splits):
     b, res = rnd(9, Co).cuda(), rnd(10, B, Co, H, W).cuda()
     xin = silu_affine(torch.cat([x0, x1], 1).cpu(), a.cpu(), s.cpu())
     ref = (F.conv2d(xin, w.cpu(), b.cpu(), padding=1) + res.cpu()) * 0.70710678
-    out = L.conv2d_nhwc(nhwc(x0), L.conv_pack_weights(w), Co, 3, 3, bias=b, src1=nhwc(x1), coef=(a, s),
+    out = L.conv2d_nhwc(nhwc(x0), L.conv_pack_weights(w, arith), Co, 3, 3, bias=b, src1=nhwc(x1), coef=(a, s),
                         act_in=L.ACT_SILU, res=nhwc(res), out_scale=0.70710678, splits=splits)
     assert rel(nchw(out), ref) < 1e-5
 
 
-def test_conv_relu_in_out_and_wide_output_row(L):
+def test_conv_relu_in_out_and_wide_output_row(L, arith):
     B, H, W, Ci, Co = 1, 8, 8, 32, 16
     x = rnd(11, B, Ci, H, W).cuda()
     w = (rnd(12, Co, Ci, 3, 3) / np.sqrt(9 * Ci)).cuda()
     ref = F.relu(F.conv2d(F.relu(x.cpu()), w.cpu(), None, padding=1))
     out = torch.full((B, H, W, 24), 7.0, device="cuda")
-    L.conv2d_nhwc(nhwc(x), L.conv_pack_weights(w), Co, 3, 3, act_in=L.ACT_RELU, act_out=L.ACT_RELU, out=out)
+    L.conv2d_nhwc(nhwc(x), L.conv_pack_weights(w, arith), Co, 3, 3, act_in=L.ACT_RELU, act_out=L.ACT_RELU, out=out)
     assert rel(nchw(out[..., :Co]), ref) < 1e-5
     assert bool((out[..., Co:] == 7.0).all())   # columns beyond Co are never written
 
 
-def test_conv_full_size_layer_vs_device_reference(L):
+def test_conv_full_size_layer_vs_device_reference(L, arith):
     """3x3 192->192 at 128x128 (the dominant layer shape), B=2, against torch on the same device."""
     B, H, W, C = 2, 128, 128, 192
     x = rnd(13, B, C, H, W).cuda()
     w = (rnd(14, C, C, 3, 3) / np.sqrt(9 * C)).cuda()
     b = rnd(15, C).cuda()
     ref = F.conv2d(x, w, b, padding=1)
-    out = L.conv2d_nhwc(nhwc(x), L.conv_pack_weights(w), C, 3, 3, bias=b)
+    out = L.conv2d_nhwc(nhwc(x), L.conv_pack_weights(w, arith), C, 3, 3, bias=b)
     assert rel(nchw(out), ref) < 2e-5
 
 
-def test_conv_fused_epilogue_moments_match_separate_pass(L):
+def test_conv_fused_epilogue_moments_match_separate_pass(L, arith):
     """per-channel {sum, sumsq} of the conv output, produced in the epilogue (full tiles) or by the fallback pass."""
     for (B, H, W, Ci, Co, fused, sp) in ((2, 16, 16, 64, 192, True, 1), (1, 8, 24, 32, 192, True, 1), (1, 8, 20, 32, 192, False, 1),
                                           (2, 16, 16, 32, 96, False, 1), (2, 8, 8, 64, 96, True, 4), (3, 8, 8, 128, 15, True, 3)):
         x = rnd(16, B, Ci, H, W).cuda()
         w = (rnd(17, Co, Ci, 3, 3) / np.sqrt(9 * Ci)).cuda()
         res = rnd(18, B, Co, H, W).cuda()
-        out, st = L.conv2d_nhwc(nhwc(x), L.conv_pack_weights(w), Co, 3, 3, res=nhwc(res), out_scale=0.7,
+        out, st = L.conv2d_nhwc(nhwc(x), L.conv_pack_weights(w, arith), Co, 3, 3, res=nhwc(res), out_scale=0.7,
                                 want_stats=True, splits=sp)
         assert (L.conv_fused_stats_splits(B, H, W, Ci, Co, 3, 3, splits=sp) > 0) == fused
         o = out.double().reshape(B, H * W, Co)
@@ -106,11 +112,34 @@ def test_conv_fused_epilogue_moments_match_separate_pass(L):
         assert rel(ca, ca2) < 1e-5 and rel(cs, cs2) < 1e-4
 
 
+def test_conv_bf16x6_is_not_less_accurate_than_f32_mfma(L):
+    """The precision claim of EVC_ARITH_BF16X6, on the real kernel: against an fp64 reference its error is no larger
+    than that of the exact-product f32 MFMA path (both accumulate in fp32), for the dominant layer shape with
+    GroupNorm+SiLU on load and for a long-K split-K layer."""
+    for (B, H, W, Ci, Co, seed) in ((1, 32, 32, 192, 192, 40), (2, 8, 8, 1536, 768, 41)):
+        x = rnd(seed, B, Ci, H, W).cuda()
+        a, s = (1 + 0.2 * rnd(seed + 1, B, Ci)).cuda(), (0.3 * rnd(seed + 2, B, Ci)).cuda()
+        w = (rnd(seed + 3, Co, Ci, 3, 3) / np.sqrt(9 * Ci)).cuda()
+        xin = F.silu(x.double() * a.double()[:, :, None, None] + s.double()[:, :, None, None])
+        ref = F.conv2d(xin, w.double(), None, padding=1)
+        err = []
+        for ar in (L.ARITH_F32, L.ARITH_BF16X6):
+            out = L.conv2d_nhwc(nhwc(x), L.conv_pack_weights(w, ar), Co, 3, 3, coef=(a, s), act_in=L.ACT_SILU)
+            e = (nchw(out).double() - ref).abs()
+            err.append((float(e.max() / ref.abs().max()), float(e.pow(2).mean().sqrt() / ref.abs().max())))
+        (mx32, rms32), (mx6, rms6) = err
+        # the on-load SiLU uses the hardware exp/rcp (~1e-7 relative), common to both paths
+        assert mx32 < 5e-6 and mx6 < 5e-6, err
+        assert rms6 <= 1.25 * rms32 and mx6 <= 2.0 * mx32, err
+
+
 def test_conv_rejects_bad_arguments(L):
     x = torch.zeros(1, 4, 4, 24, device="cuda")   # 24 channels: not a multiple of 16
     w = torch.zeros(64 * 2 * 16, device="cuda")
     with pytest.raises(L.EvcKernelError):
         L.conv2d_nhwc(x, w, 64, 3, 3)
+    with pytest.raises(L.EvcKernelError):
+        L.conv_pack_weights(torch.zeros(64, 32, 3, 3, device="cuda"), arith=7)
 
 
 @pytest.mark.parametrize("B,H,W,C,G", [(2, 16, 16, 192, 32), (3, 8, 8, 1344, 32), (1, 32, 32, 32, 8), (2, 4, 4, 160, 32)])

@@ -3,6 +3,7 @@
 // Run:    ./bench_x [layout] [iters]      prints ms and TFLOP/s for the dominant layer shapes (HIP-event timed).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 #include "../extreme-video-compression-with-prediction-using-pre-trainded-diffusion-models-_amd/csrc/conv_igemm.hip"
@@ -26,38 +27,55 @@ int main(int argc, char** argv) {
         if (only >= 0 && (int)si != only) continue;
         const Shape& s = shapes[si];
         const size_t nx = (size_t)s.B * s.R * s.R * s.Ci, no = (size_t)s.B * s.R * s.R * s.Co;
-        const size_t nw = (size_t)evc_conv_packed_floats(s.Co, s.Ci, s.K, s.K);
-        float *x, *w, *o, *ca, *cs, *ws;
-        CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&o, no * 4));
+        const size_t nraw = (size_t)s.Co * s.Ci * s.K * s.K;
+        float *x, *wraw, *o[2], *ca, *cs, *ws;
+        void* wp[2];
+        CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&wraw, nraw * 4));
         CK(hipMalloc(&ca, (size_t)s.B * s.Ci * 4)); CK(hipMalloc(&cs, (size_t)s.B * s.Ci * 4));
-        std::vector<float> h(std::max(nx, nw));
+        std::vector<float> h(std::max(nx, nraw));
         for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((int)((i * 2654435761u) >> 8 & 0xffff) - 32768) / 32768.0f;
         CK(hipMemcpy(x, h.data(), nx * 4, hipMemcpyHostToDevice));
-        for (size_t i = 0; i < nw; ++i) h[i] *= 0.02f;
-        CK(hipMemcpy(w, h.data(), nw * 4, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < nraw; ++i) h[i] *= 0.02f;
+        CK(hipMemcpy(wraw, h.data(), nraw * 4, hipMemcpyHostToDevice));
         std::vector<float> one((size_t)s.B * s.Ci, 1.0f), zero((size_t)s.B * s.Ci, 0.1f);
         CK(hipMemcpy(ca, one.data(), one.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(cs, zero.data(), zero.size() * 4, hipMemcpyHostToDevice));
-        evc_conv_args a = {};
-        a.src0 = x; a.C0 = s.Ci; a.w_packed = w; a.out = o; a.ld_out = s.Co; a.out_scale = 1.f;
-        a.B = s.B; a.H = s.R; a.W = s.R; a.Co = s.Co; a.KH = s.K; a.KW = s.K;
-        if (s.mode) { a.coef_a = ca; a.coef_s = cs; a.act_in = EVC_ACT_SILU; }
-        long long wsb = evc_conv_workspace_bytes(&a);
-        ws = nullptr;
-        if (wsb > 0) CK(hipMalloc(&ws, wsb));
-        hipEvent_t e0, e1;
-        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        for (int i = 0; i < 2; ++i) if (evc_conv2d_nhwc_f32(&a, ws, nullptr) != 0) { printf("launch failed\n"); return 1; }
-        CK(hipDeviceSynchronize());
-        CK(hipEventRecord(e0, nullptr));
-        for (int i = 0; i < iters; ++i) evc_conv2d_nhwc_f32(&a, ws, nullptr);
-        CK(hipEventRecord(e1, nullptr));
-        CK(hipEventSynchronize(e1));
-        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
-        const double flop = 2.0 * s.B * s.R * s.R * (double)s.Ci * s.Co * s.K * s.K;
-        printf("B=%d %3dx%-3d %4d->%-4d k%d %s splits=%d : %.3f ms  %.1f TF/s\n", s.B, s.R, s.R, s.Ci, s.Co, s.K,
-               s.mode ? "gn+silu" : "plain  ", evc_conv_choose_splits(&a), ms, flop / ms / 1e9);
-        hipFree(x); hipFree(w); hipFree(o); hipFree(ca); hipFree(cs); if (ws) hipFree(ws);
+        double tf[2] = {0, 0};
+        int nsplit = 0;
+        for (int arith = 0; arith < 2; ++arith) {
+            CK(hipMalloc(&o[arith], no * 4));
+            CK(hipMalloc(&wp[arith], (size_t)evc_conv_packed_bytes(s.Co, s.Ci, s.K, s.K, arith)));
+            if (evc_conv_pack_weights(wraw, wp[arith], s.Co, s.Ci, s.K, s.K, arith, nullptr) != 0) { printf("pack failed\n"); return 1; }
+            evc_conv_args a = {};
+            a.src0 = x; a.C0 = s.Ci; a.w_packed = (const float*)wp[arith]; a.out = o[arith]; a.ld_out = s.Co; a.out_scale = 1.f;
+            a.B = s.B; a.H = s.R; a.W = s.R; a.Co = s.Co; a.KH = s.K; a.KW = s.K; a.arith = arith;
+            if (s.mode) { a.coef_a = ca; a.coef_s = cs; a.act_in = EVC_ACT_SILU; }
+            long long wsb = evc_conv_workspace_bytes(&a);
+            ws = nullptr;
+            if (wsb > 0) CK(hipMalloc(&ws, wsb));
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            for (int i = 0; i < 2; ++i) if (evc_conv2d_nhwc_f32(&a, ws, nullptr) != 0) { printf("launch failed\n"); return 1; }
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < iters; ++i) evc_conv2d_nhwc_f32(&a, ws, nullptr);
+            CK(hipEventRecord(e1, nullptr));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+            const double flop = 2.0 * s.B * s.R * s.R * (double)s.Ci * s.Co * s.K * s.K;
+            tf[arith] = flop / ms / 1e9;
+            nsplit = evc_conv_choose_splits(&a);
+            if (ws) hipFree(ws);
+        }
+        std::vector<float> r0(no), r1(no);
+        CK(hipMemcpy(r0.data(), o[0], no * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(r1.data(), o[1], no * 4, hipMemcpyDeviceToHost));
+        double mx = 0, sc = 0;
+        for (size_t i = 0; i < no; ++i) { mx = std::max(mx, (double)std::fabs(r0[i] - r1[i])); sc = std::max(sc, (double)std::fabs(r0[i])); }
+        printf("B=%d %3dx%-3d %4d->%-4d k%d %s splits=%d : f32 %.1f TF/s   bf16x6 %.1f TF/s   max|diff|/max|out| %.2e\n", s.B, s.R, s.R,
+               s.Ci, s.Co, s.K, s.mode ? "gn+silu" : "plain  ", nsplit, tf[0], tf[1], mx / sc);
+        hipFree(wraw); hipFree(o[0]); hipFree(o[1]); hipFree(wp[0]); hipFree(wp[1]); float* w = nullptr; float* o_ = nullptr; (void)o_;
+        hipFree(x); hipFree(ca); hipFree(cs); (void)w;
     }
     return 0;
 }
