@@ -13,7 +13,7 @@ forwards per chunk, fp32).  Weak scaling: every GPU decodes its own 9 clips; no 
 Synthetic data, seeded random weights of the reference architecture (no checkpoints / dataset offline).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (conv_igemm_kernel<3>, f32 MFMA implicit-GEMM convolution): algorithmic
+  roofline     -- the dominant kernel (implicit-GEMM convolution, conv_split_kernel<3> / conv_igemm_kernel<3>): algorithmic
                   FLOPs per launch / average launch duration measured live with HIP events on the launch stream
   cpu_baseline -- the CPU oracle (a port, kind "port") timed on this box's host cores on a bounded sample
 """
@@ -32,6 +32,10 @@ sys.path.insert(0, REPO)
 FWD_FLOP_PER_SAMPLE = 345_201_475_584      # one score-network forward, one sample
 ELIC_DECODE_FLOP = 10.865e9                # one 128x128 key-frame decode
 F32_MFMA_PEAK_TFLOPS = 157.3               # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix == vector peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0             # same guide: dense bf16 MFMA (no sparsity)
+# EVC_ARITH_BF16X6 issues six bf16 MFMAs per fp32 product (exact 3-way operand split), so the fp32-equivalent roof of
+# that kernel is the bf16 peak / 6; `achieved` stays ALGORITHMIC fp32 FLOPs (2*M*Co*taps*Ci) per second.
+BF16X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 
 
 def parse():
@@ -72,18 +76,24 @@ def roofline_leg(net, clips, device):
         v["flops"] += r["flops"]
     dom = max(per, key=lambda k: per[k]["ms"])
     d = per[dom]
+    arith = prof[0]["arith"]
+    kname = ("conv_split_kernel" if arith == L.ARITH_BF16X6 else "conv_igemm_kernel") + f"<{dom}>"
+    peak = BF16X6_PEAK_TFLOPS if arith == L.ARITH_BF16X6 else F32_MFMA_PEAK_TFLOPS
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     total_conv_ms = sum(v["ms"] for v in per.values()) / 3
     traffic = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes (same kernel, same batch)
     try:
         pmc = json.load(open(os.path.join(REPO, "profiles", "r01_conv_pmc.json")))
-        if clips == 9 and pmc.get("kernel") == f"conv_igemm_kernel<{dom}>":
+        if clips == 9 and pmc.get("kernel") == kname:
             traffic = pmc["hbm_bytes_per_launch"]
     except Exception:
         pass
-    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "kernel": f"conv_igemm_kernel<{dom}>", "launches_per_forward": d["n"] // 3,
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic,
+            "kernel": kname, "launches_per_forward": d["n"] // 3,
+            "peak_basis": ("dense bf16 MFMA 2500 TFLOP/s / 6 MFMAs per fp32 product (exact 3-way bf16 split, fp32 "
+                           "accumulate); f32-MFMA roof would be 157.3" if arith == L.ARITH_BF16X6
+                           else "dense f32 MFMA 157.3 TFLOP/s"),
             "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 2),
             "algorithmic_gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 3),
             "conv_ms_per_forward": round(total_conv_ms, 3), "batch": clips}
@@ -176,6 +186,9 @@ def main():
     out = {"metric": "decoded frames/sec (128x128x30) at q3", "value": round(value, 4), "unit": "frames/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "arithmetic": ("fp32 in / fp32 accumulate; conv products as 6 bf16 MFMAs on an exact 3-way bf16 split of both "
+                          "operands (error vs fp64 <= the f32-MFMA path, tests/test_gpu_ops.py)"
+                          if L.default_arith() == L.ARITH_BF16X6 else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
            "config": {"workload": f"configs[1]: {a.clips} clips/GPU x 30 frames 128x128, q3, 2 ELIC key frames + "
                                   f"6 chunks x {fwd_per_chunk} forwards ({a.sampler}-{a.subsample}), B={a.clips} per launch",
                       "parallelism": f"clip-sharded dp{world}, no data-path collective; {a.groups} concurrent clip "

@@ -54,6 +54,16 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #ifndef EVC_CONV_TM1
 #define EVC_CONV_TM1 1         // 1: grids with < 64 tiles of 128 pixels use 64-pixel tiles (0 disables, for A/B)
 #endif
+#ifndef EVC_SPLIT_PIPE
+#define EVC_SPLIT_PIPE 1       // bf16x6 kernel: 1 = software-pipelined schedule (mid-step barrier, fills two steps ahead,
+                               // fragment prefetch), 0 = the simple schedule of conv_igemm_kernel (kept for A/B)
+#endif
+#ifndef EVC_SPLIT_INTERLEAVE
+#define EVC_SPLIT_INTERLEAVE 5     // bf16x6 kernel: VALU instructions scheduled per MFMA in the second half (0 = compiler's order)
+#endif
+#ifndef EVC_SPLIT_COUNTED_WAIT
+#define EVC_SPLIT_COUNTED_WAIT 1   // bf16x6 kernel: mid-step barrier leaves the in-flight activation loads outstanding
+#endif
 #ifndef EVC_CONV_PLAIN_DMA
 #define EVC_CONV_PLAIN_DMA 0   // 1: in plain mode the activation tile also goes global -> LDS by DMA (out-of-image lanes
                                // read a zero page). Measured equal to register staging on MI355X; kept as an option.
@@ -410,11 +420,13 @@ __device__ __forceinline__ void split3_bf16(const float4& v0, const float4& v1, 
     }
 }
 
+#if !EVC_SPLIT_PIPE
 template <int TM, int TN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
     constexpr int BM = 64 * TM;
     constexpr int BN = 64 * TN;
     constexpr int RB = 32;                       // bytes per LDS row: 16 bf16
+    constexpr int NWD = (6 * TN + 3) / 4;        // weight DMA instructions per wave and K-step
     constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     char* const As = smem_b;                          // [2][3][BM][32 B]
@@ -422,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform by construction: keep it scalar
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
 
@@ -434,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
 
     // ---- per-thread gather state: pixel row tid/2, channel half kh (8 channels) ----
     const int row = tid >> 1, kh = tid & 1;
-    const bool a_active = TM == 2 || row < BM;                        // wave-uniform (TM = 1: waves 0, 1)
+    const bool a_active = TM == 2 || wave < 2;                        // wave-uniform (TM = 1: rows 0..63)
     const int padH = p.KH >> 1, padW = p.KW >> 1;
     const int Ct = p.C0 + p.C1;
     unsigned off0, off1, okmask = 0;
@@ -463,6 +475,23 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
     const int fr = l31 * RB + 16 * (half ^ ((l31 >> 3) & 1));
     const int a_rd = wm * 32 * TM * RB + fr, w_rd = wn * 32 * TN * RB + fr;
 
+    // ---- weight DMA pieces of this wave (fixed): 6*TN pieces of 1 KiB (32 rows of one plane) over 4 waves; when
+    // that does not divide, the surplus waves of the last round repeat the final piece (identical bytes to the same
+    // place), which keeps the K-step free of branches ----
+    unsigned wsrc[NWD];      // per-lane byte offset inside a (tap, chunk) slab
+    int wdst[NWD];           // LDS byte offset inside a W buffer (scalar)
+#pragma unroll
+    for (int j = 0; j < NWD; ++j) {
+        const int idx = min(wave + 4 * j, 6 * TN - 1);
+        const int part = idx / (2 * TN), seg = idx - part * (2 * TN);
+        wsrc[j] = (unsigned)((part * p.CoPad + n0 + seg * 32) * RB + lane * 16);
+        wdst[j] = (part * BN + seg * 32) * RB;
+    }
+    const unsigned slab = 3u * (unsigned)p.CoPad * RB;                 // bytes per (tap, chunk)
+    const unsigned w_tap = (unsigned)p.nchunk * slab;                  // tap -> tap + 1
+    const unsigned w_wrap = slab - (unsigned)(p.KH * p.KW) * w_tap;    // last tap of chunk c -> tap 0 of chunk c + 1
+
+    // ---- "next step" cursor (chunk-major, taps inner) with incrementally maintained scalar offsets ----
     int c_chunk, c_ty, c_tx;
     {
         const int taps = p.KH * p.KW;
@@ -471,6 +500,21 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
         c_ty = tap / p.KW;
         c_tx = tap - c_ty * p.KW;
     }
+    unsigned w_off = (unsigned)((c_ty * p.KW + c_tx) * p.nchunk + c_chunk) * slab;
+    const char* a_src;       // source tensor of the cursor's chunk
+    int a_px;                // bytes per pixel of that source
+    int a_delta;             // byte offset of (tap, chunk) relative to the output pixel's channel 0
+    unsigned a_safe;         // always-legal offset (pixel 0) for out-of-image taps
+    bool a_first;
+    auto chunk_setup = [&]() {
+        const int c = c_chunk * KC;
+        a_first = c < p.C0;
+        a_src = reinterpret_cast<const char*>(a_first ? p.src0 : p.src1);
+        a_px = (a_first ? p.ld0 : p.ld1) * 4;
+        const int cc = a_first ? c : c - p.C0;
+        a_delta = ((c_ty - padH) * p.W + (c_tx - padW)) * a_px + cc * 4;
+        a_safe = (unsigned)(cc + 8 * kh) * 4u;
+    };
     float4 areg[2], ca[2], cs[2];
     bool aok = false;
 
@@ -484,36 +528,24 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
         }
     };
     auto issue_loads = [&](int buf) {
-        const int c = c_chunk * KC;
-        const bool first = c < p.C0;                              // wave-uniform
-        const char* src = reinterpret_cast<const char*>(first ? p.src0 : p.src1);
-        const int ld = first ? p.ld0 : p.ld1;
-        const int tap = c_ty * p.KW + c_tx;
-        const int delta = (((c_ty - padH) * p.W + (c_tx - padW)) * ld + (first ? c : c - p.C0)) * 4;
-        const unsigned safe = (unsigned)((first ? c : c - p.C0) + 8 * kh) * 4u;   // pixel 0: always legal
         if (a_active && !(EVC_CONV_ABLATE & 2)) {
-            aok = (okmask >> tap) & 1u;
-            const unsigned o = aok ? (first ? off0 : off1) + (unsigned)delta : safe;
-            areg[0] = *reinterpret_cast<const float4*>(src + o);
-            areg[1] = *reinterpret_cast<const float4*>(src + o + 16);
+            aok = (okmask >> (c_ty * p.KW + c_tx)) & 1u;
+            const unsigned o = aok ? (a_first ? off0 : off1) + (unsigned)a_delta : a_safe;
+            areg[0] = *reinterpret_cast<const float4*>(a_src + o);
+            areg[1] = *reinterpret_cast<const float4*>(a_src + o + 16);
         }
-        // W slab: 3 planes x BN rows x 32 B = 6*TN KiB; one wave instruction moves 1 KiB (32 rows of one plane)
-        const char* wt = reinterpret_cast<const char*>(p.w) + (size_t)(tap * p.nchunk + c_chunk) * 3 * p.CoPad * RB;
+        const char* wt = reinterpret_cast<const char*>(p.w) + w_off;
         char* wl = Ws + buf * 3 * BN * RB;
-        // (6*TN pieces over 4 waves: when that does not divide, the last round's surplus waves repeat the final
-        // piece -- identical bytes to the same place -- which keeps the K-step free of branches)
 #pragma unroll
-        for (int j = 0; j < ((EVC_CONV_ABLATE & 1) ? 0 : (6 * TN + 3) / 4); ++j) {
-            const int idx = min(wave + 4 * j, 6 * TN - 1);         // wave-uniform
-            const int part = idx / (2 * TN), seg = idx - part * (2 * TN);
-            __builtin_amdgcn_global_load_lds((glb_void*)(wt + ((size_t)part * p.CoPad + n0 + seg * 32) * RB + lane * 16),
-                                             (lds_void*)(wl + (part * BN + seg * 32) * RB), 16, 0, 0);
-        }
+        for (int j = 0; j < ((EVC_CONV_ABLATE & 1) ? 0 : NWD); ++j)
+            __builtin_amdgcn_global_load_lds((glb_void*)(wt + wsrc[j]), (lds_void*)(wl + wdst[j]), 16, 0, 0);
     };
-    auto advance = [&]() {
-        ++c_tx;
-        if (c_tx == p.KW) { c_tx = 0; ++c_ty; }
-        if (c_ty == p.KH) { c_ty = 0; ++c_chunk; }
+    // returns true when the cursor moved to a new channel chunk
+    auto advance = [&]() -> bool {
+        ++c_tx; a_delta += a_px; w_off += w_tap;
+        if (c_tx == p.KW) { c_tx = 0; ++c_ty; a_delta += (p.W - p.KW) * a_px; }
+        if (c_ty == p.KH) { c_ty = 0; ++c_chunk; w_off += w_wrap; chunk_setup(); return true; }
+        return false;
     };
     auto store_a = [&](int buf) {
         if (!a_active || (EVC_CONV_ABLATE & 2)) return;
@@ -533,6 +565,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    chunk_setup();
     if (s_begin < s_end) {
         load_coefs();
         issue_loads(0);
@@ -542,10 +575,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
 
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
+        // Always prefetch: the last iteration re-fetches its own step into the idle buffers, which keeps the
+        // body free of data-dependent control flow.
         if (s + 1 < s_end) {
-            const int prev_chunk = c_chunk;
-            advance();
-            if (HAS_COEF && c_chunk != prev_chunk) load_coefs();
+            if (advance() && HAS_COEF) load_coefs();                  // wave-uniform, once per KH*KW steps
         }
         issue_loads(buf ^ 1);
 
@@ -572,6 +605,246 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
 
     conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
 }
+#else  // EVC_SPLIT_PIPE
+// Software-pipelined schedule (default).  Iteration t of the K loop (local step index), buffers cur = t & 1,
+// nxt = cur ^ 1:
+//     top          read the fragments of step t that were not prefetched (a1, b1, a0, b2) from cur -- no barrier
+//                  in front of them, their latency sits behind the first MFMA term (a2 x b0, prefetched)
+//     terms 1-3    18 MFMAs
+//     BARRIER      (a) every wave has all of step t's fragments in registers -> cur may be overwritten,
+//                  (b) publishes nxt = step t+1 (filled during the previous iteration's second half)
+//     second half  fill cur with step t+2: weight slab by LDS-DMA, activation tile from the registers loaded one
+//                  iteration ago (transform + split + ds_write); issue the activation loads of step t+3;
+//                  prefetch a2, b0 of step t+1 from nxt into the registers a2 / b2 just vacated
+//     terms 4-6    18 MFMAs
+// So every global load and every DMA has a full iteration to land, fragment-read latency is never exposed behind
+// a barrier, and there is still exactly one barrier per K-step and two LDS buffers.
+template <int TM, int TN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
+    constexpr int BM = 64 * TM;
+    constexpr int BN = 64 * TN;
+    constexpr int RB = 32;                       // bytes per LDS row: 16 bf16
+    constexpr int NWD = (6 * TN + 3) / 4;        // weight DMA instructions per wave and K-step
+    constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    char* const As = smem_b;                          // [2][3][BM][32 B]
+    char* const Ws = smem_b + 2 * 3 * BM * RB;        // [2][3][BN][32 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform by construction: keep it scalar
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int split = blockIdx.z;
+    const int s_begin = split * p.steps_per_split;
+    const int nst = min(p.nsteps, s_begin + p.steps_per_split) - s_begin;     // K-steps of this workgroup
+
+    // ---- per-thread gather state: pixel row tid/2, channel half kh (8 channels) ----
+    const int row = tid >> 1, kh = tid & 1;
+    const bool a_active = TM == 2 || wave < 2;                        // wave-uniform (TM = 1: rows 0..63)
+    const int padH = p.KH >> 1, padW = p.KW >> 1;
+    const int Ct = p.C0 + p.C1;
+    unsigned off0, off1, okmask = 0;
+    int rb;
+    {
+        const int m = m0 + row;
+        const bool valid = a_active && m < p.M;
+        const int mm = valid ? m : 0;
+        const int b = mm / p.HW;
+        const int rem = mm - b * p.HW;
+        const int y = rem / p.W;
+        const int x = rem - y * p.W;
+        rb = b;
+        off0 = ((unsigned)mm * (unsigned)p.ld0 + 8u * kh) * 4u;
+        off1 = ((unsigned)mm * (unsigned)p.ld1 + 8u * kh) * 4u;
+        for (int ty = 0; ty < p.KH; ++ty)
+            for (int tx = 0; tx < p.KW; ++tx) {
+                const int yy = y + ty - padH, xx = x + tx - padW;
+                const bool ok = valid && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                okmask |= (ok ? 1u : 0u) << (ty * p.KW + tx);
+            }
+    }
+    const int a_lds = row * RB + 16 * (kh ^ ((row >> 3) & 1));        // byte offset inside one plane
+    const int fr = l31 * RB + 16 * (half ^ ((l31 >> 3) & 1));
+    const int a_rd = wm * 32 * TM * RB + fr, w_rd = wn * 32 * TN * RB + fr;
+
+    // ---- weight DMA pieces of this wave (fixed): 6*TN pieces of 1 KiB (32 rows of one plane) over 4 waves; when
+    // that does not divide, the surplus waves of the last round repeat the final piece (identical bytes to the same
+    // place), which keeps the K-step free of branches ----
+    unsigned wsrc[NWD];
+    int wdst[NWD];
+#pragma unroll
+    for (int j = 0; j < NWD; ++j) {
+        const int idx = min(wave + 4 * j, 6 * TN - 1);
+        const int part = idx / (2 * TN), seg = idx - part * (2 * TN);
+        wsrc[j] = (unsigned)((part * p.CoPad + n0 + seg * 32) * RB + lane * 16);
+        wdst[j] = (part * BN + seg * 32) * RB;
+    }
+    const unsigned slab = 3u * (unsigned)p.CoPad * RB;                 // bytes per (tap, chunk)
+    const unsigned w_tap = (unsigned)p.nchunk * slab;                  // tap -> tap + 1
+    const unsigned w_wrap = slab - (unsigned)(p.KH * p.KW) * w_tap;    // last tap of chunk c -> tap 0 of chunk c + 1
+
+    // ---- two cursors over the K-steps (chunk-major, taps inner): W (weight DMA) and L (activation loads) ----
+    int w_ty, w_tx, l_chunk, l_ty, l_tx;
+    {
+        const int taps = p.KH * p.KW;
+        l_chunk = s_begin / taps;
+        const int tap = s_begin - l_chunk * taps;
+        l_ty = w_ty = tap / p.KW;
+        l_tx = w_tx = tap - l_ty * p.KW;
+    }
+    unsigned w_off = (unsigned)((w_ty * p.KW + w_tx) * p.nchunk + l_chunk) * slab;
+    const char* a_src; int a_px, a_delta; unsigned a_safe; bool a_first;
+    auto chunk_setup = [&]() {
+        const int c = l_chunk * KC;
+        a_first = c < p.C0;
+        a_src = reinterpret_cast<const char*>(a_first ? p.src0 : p.src1);
+        a_px = (a_first ? p.ld0 : p.ld1) * 4;
+        const int cc = a_first ? c : c - p.C0;
+        a_delta = ((l_ty - padH) * p.W + (l_tx - padW)) * a_px + cc * 4;
+        a_safe = (unsigned)(cc + 8 * kh) * 4u;
+    };
+    float4 areg[2], ca[2], cs[2];
+    bool aok = false;
+    auto load_coefs = [&]() {
+        if (HAS_COEF) {
+            const size_t co = (size_t)rb * Ct + l_chunk * KC + 8 * kh;
+            ca[0] = *reinterpret_cast<const float4*>(p.coef_a + co);
+            ca[1] = *reinterpret_cast<const float4*>(p.coef_a + co + 4);
+            cs[0] = *reinterpret_cast<const float4*>(p.coef_s + co);
+            cs[1] = *reinterpret_cast<const float4*>(p.coef_s + co + 4);
+        }
+    };
+    auto load_a = [&]() {                                              // activation loads of the step L points at
+        if (a_active && !(EVC_CONV_ABLATE & 2)) {
+            aok = (okmask >> (l_ty * p.KW + l_tx)) & 1u;
+            const unsigned o = aok ? (a_first ? off0 : off1) + (unsigned)a_delta : a_safe;
+            areg[0] = *reinterpret_cast<const float4*>(a_src + o);
+            areg[1] = *reinterpret_cast<const float4*>(a_src + o + 16);
+        }
+    };
+    auto dma_w = [&](int buf) {                                        // weight slab of the step W points at
+        const char* wt = reinterpret_cast<const char*>(p.w) + w_off;
+        char* wl = Ws + buf * 3 * BN * RB;
+#pragma unroll
+        for (int j = 0; j < ((EVC_CONV_ABLATE & 1) ? 0 : NWD); ++j)
+            __builtin_amdgcn_global_load_lds((glb_void*)(wt + wsrc[j]), (lds_void*)(wl + wdst[j]), 16, 0, 0);
+    };
+    auto advance_w = [&]() {
+        ++w_tx; w_off += w_tap;
+        if (w_tx == p.KW) { w_tx = 0; ++w_ty; }
+        if (w_ty == p.KH) { w_ty = 0; w_off += w_wrap; }
+    };
+    // the coefficients are (re)loaded when L enters a new chunk; the next store_a is the one that consumes the
+    // data L now points at, so `ca / cs` always match the registers being stored
+    auto advance_l = [&]() {
+        ++l_tx; a_delta += a_px;
+        if (l_tx == p.KW) { l_tx = 0; ++l_ty; a_delta += (p.W - p.KW) * a_px; }
+        if (l_ty == p.KH) { l_ty = 0; ++l_chunk; chunk_setup(); load_coefs(); }
+    };
+    auto store_a = [&](int buf) {
+        if (!a_active || (EVC_CONV_ABLATE & 2)) return;
+        bf16x8 p1, p2, p3;
+        split3_bf16(transform<MODE>(areg[0], ca[0], cs[0], aok), transform<MODE>(areg[1], ca[1], cs[1], aok), p1, p2, p3);
+        char* A = As + buf * 3 * BM * RB + a_lds;
+        *reinterpret_cast<bf16x8*>(A) = p1;
+        *reinterpret_cast<bf16x8*>(A + BM * RB) = p2;
+        *reinterpret_cast<bf16x8*>(A + 2 * BM * RB) = p3;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    bf16x8 a[TM][3], b[TN][3], bp[TN];      // bp: b0 of the NEXT step (prefetched into the space b2 vacates)
+    if (nst > 0) {
+        // ---- prologue: steps 0 and 1 into buffers 0 and 1, activation registers of step 2 in flight ----
+        chunk_setup();
+        load_coefs();
+        load_a();
+        dma_w(0);
+        store_a(0);
+        if (1 < nst) { advance_l(); advance_w(); }
+        load_a();
+        dma_w(1);
+        store_a(1);
+        if (2 < nst) { advance_l(); advance_w(); }
+        load_a();
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i][2] = *reinterpret_cast<const bf16x8*>(As + a_rd + (2 * BM + i * 32) * RB);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bp[j] = *reinterpret_cast<const bf16x8*>(Ws + w_rd + (0 * BN + j * 32) * RB);
+    }
+
+#define EVC_SPLIT_TERM(qa, qb)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
+    for (int t = 0; t < nst; ++t) {
+        const int cur = t & 1;
+        const char* Ab = As + cur * 3 * BM * RB + a_rd;
+        const char* Wb = Ws + cur * 3 * BN * RB + w_rd;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j][0] = bp[j];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i][1] = *reinterpret_cast<const bf16x8*>(Ab + (1 * BM + i * 32) * RB);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j][1] = *reinterpret_cast<const bf16x8*>(Wb + (1 * BN + j * 32) * RB);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i][0] = *reinterpret_cast<const bf16x8*>(Ab + (0 * BM + i * 32) * RB);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j][2] = *reinterpret_cast<const bf16x8*>(Wb + (2 * BN + j * 32) * RB);
+        EVC_SPLIT_TERM(2, 0) EVC_SPLIT_TERM(1, 1) EVC_SPLIT_TERM(0, 2)
+        // Barrier.  vmcnt counts in issue order and this wave's two YOUNGEST vector-memory operations are the
+        // activation loads of step t + 2 (issued at the end of the previous second half, consumed by store_a
+        // below): wait for everything older -- the weight DMA into nxt -- but leave those two in flight.
+        // (__syncthreads would drain them too: a false dependency of ~one memory latency per K-step.)
+#if EVC_SPLIT_COUNTED_WAIT
+        __builtin_amdgcn_sched_barrier(0);          // the 18 MFMAs above stay above (they are not memory operations)
+        if (a_active && !(EVC_CONV_ABLATE & 2)) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#else
+        __syncthreads();
+#endif
+        // ---- second half (one basic block): fill `cur` with step t + 2, prefetch a2 / b0 of step t + 1 from `nxt`;
+        // the staging arithmetic (transform + split) is spread over the gaps of the 18 MFMAs ----
+        dma_w(cur);
+        const char* An = As + (cur ^ 1) * 3 * BM * RB + a_rd;
+        const char* Wn = Ws + (cur ^ 1) * 3 * BN * RB + w_rd;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i][2] = *reinterpret_cast<const bf16x8*>(An + (2 * BM + i * 32) * RB);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bp[j] = *reinterpret_cast<const bf16x8*>(Wn + (0 * BN + j * 32) * RB);
+        store_a(cur);
+        EVC_SPLIT_TERM(1, 0) EVC_SPLIT_TERM(0, 1) EVC_SPLIT_TERM(0, 0)
+#if EVC_SPLIT_INTERLEAVE
+        __builtin_amdgcn_sched_group_barrier(0x010, NWD, 0);          // weight DMA
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);      // prefetch reads
+#pragma unroll
+        for (int g = 0; g < 6 * TM * TN / 2; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one MFMA ...
+            __builtin_amdgcn_sched_group_barrier(0x002, EVC_SPLIT_INTERLEAVE, 0);   // ... a few VALU in its shadow
+        }
+#endif
+        // ---- cursors for the next iteration (scalar, occasionally branchy: kept out of the block above), then the
+        // activation loads of step t + 3 -- the two youngest vector-memory operations at the next barrier ----
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 3 < nst) { advance_w(); advance_l(); }
+        load_a();
+    }
+#undef EVC_SPLIT_TERM
+
+    conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
+}
+#endif  // EVC_SPLIT_PIPE
 
 #if EVC_CONV_PC
 // Producer / consumer specialisation of the same tiling (128 x 64*TN tile, TM = 2).  A workgroup has 8 waves:
