@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--clips", type=int, default=9, help="clips per GPU per step (configs[1]: start 0 end 8)")
     ap.add_argument("--subsample", type=int, default=100)
     ap.add_argument("--sampler", default="DDPM", choices=["DDPM", "DDIM", "FPNDM"])
-    ap.add_argument("--groups", type=int, default=2,
+    ap.add_argument("--groups", type=int, default=1,
                     help="concurrent clip groups per GPU during generation (one HIP stream each)")
     ap.add_argument("--preactivate", action="store_true",
                     help="apply AdaGN+SiLU once per tensor in its own pass instead of inside the conv operand load")

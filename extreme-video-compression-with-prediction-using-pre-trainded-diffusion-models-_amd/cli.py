@@ -52,7 +52,7 @@ def build_parser():
     p.add_argument("--synthetic", action="store_true", help="seeded stand-ins for missing checkpoints / data")
     p.add_argument("--batch", type=int, default=8,
                    help="mask policy: clips decoded together per GPU (the reference runs one clip at a time)")
-    p.add_argument("--groups", type=int, default=2, help="concurrent clip groups (HIP streams) inside a batch")
+    p.add_argument("--groups", type=int, default=1, help="concurrent clip groups (HIP streams) inside a batch")
     p.add_argument("--bitstream-dir", type=str, default=None,
                    help="mask policy: write each batch's key-frame strings + mask as an EVC1 container here and "
                         "decode from the bytes read back (container.py)")

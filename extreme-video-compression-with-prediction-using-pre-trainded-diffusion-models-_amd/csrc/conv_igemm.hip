@@ -1373,6 +1373,44 @@ static int conv_validate(const evc_conv_args* a) {
 // write + combine traffic and no half-empty tiles (A/B: 8x8 768->768 58 -> 69 TFLOP/s; on mid-size grids such
 // as 32x32 576->576 the smaller tile loses, 92 -> 84, so it is not used there).
 struct TileCfg { int tm, tn, bm, bn; long long tiles; int splits; int reuse; int steps_per_split; };
+static int g_force_tm = 0;     // tools/conv_bench.hip (same translation unit) sets this to sweep tile heights; never set in the library
+
+// bf16x6 kernel: 2 workgroups per CU (60 KB LDS each) = 512 slots, and a workgroup's speed is set by its own
+// dependency chain, not by how many share the CU, so the grid behaves like rounds of 512 equal jobs.  The choice
+// below scores every (tile height, split factor) by
+//     round efficiency x/ceil(x), x = workgroups / 512          (a 1.1-round grid wastes half the machine)
+//   * steps / (steps + 6)                                       (prologue + epilogue of a workgroup ~ 6 K-steps)
+//   * 0.75 for 64-pixel tiles of multi-tap filters              (twice the weight traffic per MFMA; measured ~0.8)
+//   / (1 + c * splits / K)                                      (slab write + combine read: 8 B per output element
+//                                                                and split against 2*K FLOP; c = 40 while the slabs
+//                                                                stay in L2 / MALL, 300 beyond 192 MB)
+// and was checked against a measured sweep on MI355X (tools/conv_bench.hip, mode 2): it picks
+// the measured optimum or a configuration within a few percent of it for every layer shape of the network at
+// B = 4, 5 and 9 (e.g. 64x64 192->192, B=9: splits 3 instead of 2, 139 -> 161 TFLOP/s; 32x32 384->384: 4 -> 3,
+// 141 -> 171).
+static void split_tile_cfg(const evc_conv_args* a, long long M, long long ntile, int nsteps, TileCfg& c) {
+    const double K = (double)a->KH * a->KW * (a->C0 + a->C1);
+    double best = -1.0;
+    int best_tm = 2, best_s = 1;
+    for (int tm = 2; tm >= 1; --tm) {
+        if (g_force_tm && tm != g_force_tm) continue;
+        const long long tiles = ((M + 64 * tm - 1) / (64 * tm)) * ntile;
+        const int smax = a->splits > 0 ? a->splits : (nsteps / 4 < 1 ? 1 : (nsteps / 4 > 32 ? 32 : nsteps / 4));
+        for (int s = a->splits > 0 ? a->splits : 1; s <= smax; ++s) {
+            const double x = (double)tiles * s / 512.0;
+            const double eff = x <= 1.0 ? x : x / (double)(long long)(x + 0.999999);
+            const double sps = (double)((nsteps + s - 1) / s);
+            const double slab_mb = (double)s * (double)M * a->Co * 4.0 / 1e6;
+            const double pen = s > 1 ? 1.0 + (slab_mb > 192.0 ? 300.0 : 40.0) * s / K : 1.0;
+            const double score = eff * sps / (sps + 6.0) * (tm == 1 && a->KH * a->KW > 1 ? 0.75 : 1.0) / pen;
+            if (score > best * 1.0001) { best = score; best_tm = tm; best_s = s; }
+        }
+    }
+    c.tm = best_tm;
+    c.bm = 64 * c.tm;
+    c.tiles = ((M + c.bm - 1) / c.bm) * ntile;
+    c.splits = best_s;
+}
 
 static TileCfg conv_tile_cfg(const evc_conv_args* a) {
     TileCfg c;
@@ -1381,29 +1419,32 @@ static TileCfg conv_tile_cfg(const evc_conv_args* a) {
     c.tn = pick_tn(CoPad);
     c.bn = 64 * c.tn;
     const long long ntile = CoPad / c.bn;
-    c.tm = (!EVC_CONV_TM1 || ((M + 127) / 128) * ntile >= 64) ? 2 : 1;
-    c.bm = 64 * c.tm;
-    c.tiles = ((M + c.bm - 1) / c.bm) * ntile;
     const int nsteps = a->KH * a->KW * ((a->C0 + a->C1) / KC);
-    long long splits = 1;
-    if (a->splits > 0) splits = a->splits;
-    else if (c.tiles < 384) {
-        splits = (640 + c.tiles / 2) / c.tiles;
-        const int max_by_steps = nsteps / 8 > 0 ? nsteps / 8 : 1;
-        if (splits > max_by_steps) splits = max_by_steps;
-        if (splits > 32) splits = 32;
-        if (splits < 1) splits = 1;
-    }
-    c.splits = (int)splits;
-    // Row-reuse kernel: multi-tap filters whose tiles are whole image rows; a split must cover whole chunks, so
-    // round the steps per split up to a multiple of the tap count (the effective split count may shrink).
     c.reuse = 0;
+    if (a->arith == EVC_ARITH_BF16X6) {
+        split_tile_cfg(a, M, ntile, nsteps, c);
+    } else {
+        c.tm = (!EVC_CONV_TM1 || ((M + 127) / 128) * ntile >= 64) ? 2 : 1;
+        if (g_force_tm) c.tm = g_force_tm;
+        c.bm = 64 * c.tm;
+        c.tiles = ((M + c.bm - 1) / c.bm) * ntile;
+        long long splits = 1;
+        if (a->splits > 0) splits = a->splits;
+        else if (c.tiles < 384) {
+            splits = (640 + c.tiles / 2) / c.tiles;
+            const int max_by_steps = nsteps / 8 > 0 ? nsteps / 8 : 1;
+            if (splits > max_by_steps) splits = max_by_steps;
+            if (splits > 32) splits = 32;
+            if (splits < 1) splits = 1;
+        }
+        c.splits = (int)splits;
+        // Row-reuse kernel: multi-tap filters whose tiles are whole image rows; a split must cover whole chunks, so
+        // round the steps per split up to a multiple of the tap count (the effective split count may shrink).
 #if EVC_CONV_ROWREUSE
-    const int taps = a->KH * a->KW;
-    if (taps > 1 && a->KH <= 3 && a->KW <= 3 && c.bm % a->W == 0) {
-        c.reuse = 1;
-    }
+        const int taps = a->KH * a->KW;
+        if (taps > 1 && a->KH <= 3 && a->KW <= 3 && c.bm % a->W == 0) c.reuse = 1;
 #endif
+    }
     const int unit = c.reuse ? a->KH * a->KW : 1;
     int sps = (nsteps + c.splits - 1) / c.splits;
     sps = (sps + unit - 1) / unit * unit;

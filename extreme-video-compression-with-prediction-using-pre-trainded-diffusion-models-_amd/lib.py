@@ -391,12 +391,12 @@ def conv2d_nhwc(src0, w_packed, Co, KH, KW, bias=None, src1=None, coef=None, act
     return result
 
 
-def conv_fused_stats_splits(B, H, W, Ci, Co, KH, KW, splits=0):
-    """HW/64 when ``conv2d_nhwc(..., want_stats=True)`` gets its moments from the conv epilogue for this shape,
-    0 when it falls back to a separate ``evc_chan_stats_f32`` pass (C query, no launch)."""
+def conv_fused_stats_splits(B, H, W, Ci, Co, KH, KW, splits=0, arith=None):
+    """HW/64 or HW/32 when ``conv2d_nhwc(..., want_stats=True)`` gets its moments from the conv epilogue / split-K
+    combine for this shape, 0 when it falls back to a separate ``evc_chan_stats_f32`` pass (C query, no launch)."""
     d = c_void_p(16)   # any non-null pointers: the query validates shapes only
     a = ConvArgs(d, None, Ci, 0, 0, 0, None, None, ACT_NONE, d, None, None, 0, 1.0, ACT_NONE, d, Co, B, H, W, Co, KH,
-                 KW, splits, None, ARITH_F32)
+                 KW, splits, None, default_arith() if arith is None else arith)
     return hip_lib(require_device=False).evc_conv_stats_splits(ctypes.byref(a))
 
 

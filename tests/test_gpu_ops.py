@@ -100,7 +100,7 @@ def test_conv_fused_epilogue_moments_match_separate_pass(L, arith):
         res = rnd(18, B, Co, H, W).cuda()
         out, st = L.conv2d_nhwc(nhwc(x), L.conv_pack_weights(w, arith), Co, 3, 3, res=nhwc(res), out_scale=0.7,
                                 want_stats=True, splits=sp)
-        assert (L.conv_fused_stats_splits(B, H, W, Ci, Co, 3, 3, splits=sp) > 0) == fused
+        assert (L.conv_fused_stats_splits(B, H, W, Ci, Co, 3, 3, splits=sp, arith=arith) > 0) == fused
         o = out.double().reshape(B, H * W, Co)
         ref = torch.stack([o.sum(1), (o * o).sum(1)], -1).float().cpu()          # (B, Co, 2)
         got = st.double().sum(1).float().cpu()

@@ -23,6 +23,57 @@ int main(int argc, char** argv) {
                                  {9, 8, 768, 768, 3, 1}, {9, 64, 192, 192, 3, 1}, {9, 32, 384, 384, 3, 1},
                                  {9, 32, 576, 576, 3, 1}, {9, 8, 768, 768, 1, 0}, {9, 64, 384, 192, 3, 1}};
     printf("# conv_bench layout=%d iters=%d\n", layout, iters);
+    if (layout == 2) {
+        // sweep of (tile height, split factor) for the mid-size layers under bf16x6: prints the measured table
+        struct S2 { int R, Ci, Co, K; };
+        const S2 ss[] = {{64, 192, 192, 3}, {64, 384, 192, 3}, {64, 384, 384, 3}, {32, 384, 384, 3}, {32, 576, 576, 3},
+                         {16, 576, 576, 3}, {16, 768, 768, 3}, {8, 768, 768, 3}, {8, 1536, 768, 3}, {32, 384, 1152, 1},
+                         {16, 576, 1728, 1}, {8, 768, 2304, 1}, {8, 768, 768, 1}, {16, 576, 576, 1}};
+        const int Bs[] = {9, 5, 4};
+        const int sp[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
+        for (const S2& q : ss) for (int B : Bs) {
+            const size_t nx = (size_t)B * q.R * q.R * q.Ci, no = (size_t)B * q.R * q.R * q.Co, nraw = (size_t)q.Co * q.Ci * q.K * q.K;
+            float *x, *wraw, *o, *ca, *cs; void* wp;
+            CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&wraw, nraw * 4)); CK(hipMalloc(&o, no * 4));
+            CK(hipMalloc(&ca, (size_t)B * q.Ci * 4)); CK(hipMalloc(&cs, (size_t)B * q.Ci * 4));
+            CK(hipMemset(x, 0x3c, nx * 4)); CK(hipMemset(wraw, 0x3b, nraw * 4)); CK(hipMemset(ca, 0x3c, (size_t)B * q.Ci * 4)); CK(hipMemset(cs, 0x3b, (size_t)B * q.Ci * 4));
+            CK(hipMalloc(&wp, (size_t)evc_conv_packed_bytes(q.Co, q.Ci, q.K, q.K, 1)));
+            evc_conv_pack_weights(wraw, wp, q.Co, q.Ci, q.K, q.K, 1, nullptr);
+            float* ws; CK(hipMalloc(&ws, (size_t)24 * no * 4 > ((size_t)1 << 31) ? ((size_t)1 << 31) : (size_t)24 * no * 4));
+            evc_conv_args a = {};
+            a.src0 = x; a.C0 = q.Ci; a.w_packed = (const float*)wp; a.out = o; a.ld_out = q.Co; a.out_scale = 1.f;
+            a.B = B; a.H = q.R; a.W = q.R; a.Co = q.Co; a.KH = q.K; a.KW = q.K; a.arith = 1;
+            if (q.K == 3) { a.coef_a = ca; a.coef_s = cs; a.act_in = EVC_ACT_SILU; }
+            g_force_tm = 0; a.splits = 0;
+            const int def_splits = evc_conv_choose_splits(&a);
+            const int def_tm = conv_tile_cfg(&a).tm;
+            double best = 0, deftf = 0; int btm = 0, bsp = 0;
+            char line[1024]; int off = 0;
+            for (int tm = 1; tm <= 2; ++tm) for (int spi : sp) {
+                g_force_tm = tm; a.splits = spi;
+                if ((long long)spi * no * 4 > ((long long)1 << 31)) continue;
+                const int nsteps = q.K * q.K * q.Ci / 16;
+                if (spi > nsteps / 4) continue;
+                hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                if (evc_conv2d_nhwc_f32(&a, ws, nullptr) != 0) continue;
+                evc_conv2d_nhwc_f32(&a, ws, nullptr);
+                CK(hipEventRecord(e0, nullptr));
+                for (int i = 0; i < iters; ++i) evc_conv2d_nhwc_f32(&a, ws, nullptr);
+                CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+                const double tf = 2.0 * B * q.R * q.R * (double)q.Ci * q.Co * q.K * q.K / ms / 1e9;
+                if (tf > best) { best = tf; btm = tm; bsp = spi; }
+                if (tm == def_tm && spi == def_splits) deftf = tf;
+                off += snprintf(line + off, sizeof(line) - off, " %d/%d:%.0f", tm, spi, tf);
+            }
+            const long long M = (long long)B * q.R * q.R;
+            printf("B=%d %3dx%-3d %4d->%-4d k%d tiles128=%lld ntile=%d | default tm%d sp%d %.0f | best tm%d sp%d %.0f |%s\n", B, q.R, q.R, q.Ci, q.Co, q.K,
+                   (M + 127) / 128, evc_conv_co_pad(q.Co) / (64 * pick_tn(evc_conv_co_pad(q.Co))), def_tm, def_splits, deftf, btm, bsp, best, line);
+            fflush(stdout);
+            hipFree(x); hipFree(wraw); hipFree(o); hipFree(ca); hipFree(cs); hipFree(wp); hipFree(ws);
+        }
+        return 0;
+    }
     for (size_t si = 0; si < shapes.size(); ++si) {
         if (only >= 0 && (int)si != only) continue;
         const Shape& s = shapes[si];
