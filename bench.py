@@ -83,7 +83,7 @@ def roofline_leg(net, clips, device):
     total_conv_ms = sum(v["ms"] for v in per.values()) / 3
     traffic = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes (same kernel, same batch)
     try:
-        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_conv_pmc.json")))
+        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_conv_split_pmc.json" if arith == L.ARITH_BF16X6 else "r01_conv_pmc.json")))
         if clips == 9 and pmc.get("kernel") == kname:
             traffic = pmc["hbm_bytes_per_launch"]
     except Exception:

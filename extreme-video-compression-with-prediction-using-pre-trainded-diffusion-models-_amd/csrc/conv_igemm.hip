@@ -58,6 +58,12 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #define EVC_SPLIT_PIPE 1       // bf16x6 kernel: 1 = software-pipelined schedule (mid-step barrier, fills two steps ahead,
                                // fragment prefetch), 0 = the simple schedule of conv_igemm_kernel (kept for A/B)
 #endif
+#ifndef EVC_SPLIT_PC
+#define EVC_SPLIT_PC 0         // bf16x6: 128-pixel tiles run on the producer/consumer kernel (8 waves, 1 workgroup per CU)
+#endif
+#ifndef EVC_PC_CONSUMER_PRIO
+#define EVC_PC_CONSUMER_PRIO 3
+#endif
 #ifndef EVC_SPLIT_INTERLEAVE
 #define EVC_SPLIT_INTERLEAVE 5     // bf16x6 kernel: VALU instructions scheduled per MFMA in the second half (0 = compiler's order)
 #endif
@@ -707,7 +713,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
         a_delta = ((l_ty - padH) * p.W + (l_tx - padW)) * a_px + cc * 4;
         a_safe = (unsigned)(cc + 8 * kh) * 4u;
     };
-    float4 areg[2], ca[2], cs[2];
+    float4 areg[2] = {}, ca[2], cs[2];
     bool aok = false;
     auto load_coefs = [&]() {
         if (HAS_COEF) {
@@ -722,8 +728,13 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
         if (a_active && !(EVC_CONV_ABLATE & 2)) {
             aok = (okmask >> (l_ty * p.KW + l_tx)) & 1u;
             const unsigned o = aok ? (a_first ? off0 : off1) + (unsigned)a_delta : a_safe;
+#if EVC_CONV_ABLATE & 8     // diagnostic: no global loads, the staging arithmetic still runs on laundered registers
+            asm volatile("" : "+v"(areg[0].x), "+v"(areg[0].y), "+v"(areg[0].z), "+v"(areg[0].w));
+            asm volatile("" : "+v"(areg[1].x), "+v"(areg[1].y), "+v"(areg[1].z), "+v"(areg[1].w) : "v"(o));
+#else
             areg[0] = *reinterpret_cast<const float4*>(a_src + o);
             areg[1] = *reinterpret_cast<const float4*>(a_src + o + 16);
+#endif
         }
     };
     auto dma_w = [&](int buf) {                                        // weight slab of the step W points at
@@ -748,7 +759,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
     auto store_a = [&](int buf) {
         if (!a_active || (EVC_CONV_ABLATE & 2)) return;
         bf16x8 p1, p2, p3;
+#if EVC_CONV_ABLATE & 4     // diagnostic: loads kept, no transform / split (raw bits to the three planes)
+        union { float4 f[2]; bf16x8 h[2]; } raw; raw.f[0] = areg[0]; raw.f[1] = areg[1];
+        p1 = raw.h[0]; p2 = raw.h[1]; p3 = raw.h[0];
+#else
         split3_bf16(transform<MODE>(areg[0], ca[0], cs[0], aok), transform<MODE>(areg[1], ca[1], cs[1], aok), p1, p2, p3);
+#endif
         char* A = As + buf * 3 * BM * RB + a_lds;
         *reinterpret_cast<bf16x8*>(A) = p1;
         *reinterpret_cast<bf16x8*>(A + BM * RB) = p2;
@@ -845,6 +861,242 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
     conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
 }
 #endif  // EVC_SPLIT_PIPE
+
+#if EVC_SPLIT_PC
+// ---------------------------------------------------------------------------------------------------------------
+// Producer / consumer form of the bf16x6 convolution (128 x 64*TN tile, one 8-wave workgroup per CU).
+//
+// Why: in conv_split_kernel both waves of a SIMD run the same program, fall into step with each other and the
+// MFMA pipe idles whenever both are staging (measured: pipe 49 % busy at 2 workgroups per CU although no single
+// resource is saturated -- L2 -> CU traffic 6.1 TB/s of ~17, TA 28 %, LDS ~30 %).  Here the roles are split:
+//   waves 0-3  CONSUMERS  ds_read_b128 fragments + 36 MFMAs per K-step, nothing else, raised priority; the fragments
+//                         of step t+1 are read while the MFMAs of step t run (two register sets, loop unrolled by 2)
+//   waves 4-7  PRODUCERS  activation gather -> GroupNorm/SiLU -> exact 3-way bf16 split -> LDS, weight slabs by
+//                         LDS-DMA, through a ring of NS = 5 LDS stages (150 KB).  Every load and every DMA is issued
+//                         TWO K-steps before it is needed (one step is ~0.6 us, an L2 / MALL round trip under load
+//                         is longer): two alternating register sets for the activations, and a COUNTED vmcnt wait
+//                         that leaves the two youngest iterations' operations in flight.
+// Waves w and w + 4 share a SIMD, so every SIMD hosts one of each and the producer's VALU / memory instructions issue
+// in the shadow of the consumer's MFMAs.  One barrier per K-step: barrier(t+1) publishes stage t+2 and tells the
+// producers that the consumers have the fragments of step t+1 in registers.
+template <int TN, int MODE>
+__global__ __launch_bounds__(512, 1) void conv_split_pc_kernel(ConvK p) {
+    constexpr int TM = 2;
+    constexpr int BM = 128;
+    constexpr int BN = 64 * TN;
+    constexpr int RB = 32;
+    constexpr int NS = 5;
+    constexpr int STAGE = 3 * (BM + BN) * RB;            // bytes per ring stage: A planes, then W planes
+    constexpr int WOFF = 3 * BM * RB;                    // W planes inside a stage
+    constexpr int NWD = (6 * TN + 3) / 4;                // weight DMA instructions per producer wave and K-step
+    constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
+    constexpr int VOPS = NWD + 2 + (HAS_COEF ? 4 : 0);   // vector-memory operations a producer wave issues per K-step
+    constexpr int VWAIT = EVC_CONV_ABLATE ? 0 : 2 * VOPS;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int split = blockIdx.z;
+    const int s_begin = split * p.steps_per_split;
+    const int nst = min(p.nsteps, s_begin + p.steps_per_split) - s_begin;
+
+    if (wave < 4) {
+        // ================================ consumer ================================
+        __builtin_amdgcn_s_setprio(EVC_PC_CONSUMER_PRIO);
+        const int wm = wave >> 1, wn = wave & 1;
+        const int l31 = lane & 31, half = lane >> 5;
+        const int fr = l31 * RB + 16 * (half ^ ((l31 >> 3) & 1));
+        const char* const a_base = smem_b + wm * 32 * TM * RB + fr;
+        const char* const w_base = smem_b + WOFF + wn * 32 * TN * RB + fr;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        bf16x8 a0[TM][3], b0[TN][3], a1[TM][3], b1[TN][3];
+
+#define EVC_PC_READ(A, B, SOFF)                                                                              \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                      \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
+                A[i][q] = *reinterpret_cast<const bf16x8*>(a_base + (SOFF) + (q * BM + i * 32) * RB);        \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
+                B[j][q] = *reinterpret_cast<const bf16x8*>(w_base + (SOFF) + (q * BN + j * 32) * RB);        \
+        }
+#define EVC_PC_TERM(A, B, qa, qb)                                                                            \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)       \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][qa], B[j][qb], acc[i][j], 0, 0, 0);
+#define EVC_PC_MFMAS(A, B)                                                                                   \
+        EVC_PC_TERM(A, B, 2, 0) EVC_PC_TERM(A, B, 1, 1) EVC_PC_TERM(A, B, 0, 2)                              \
+        EVC_PC_TERM(A, B, 1, 0) EVC_PC_TERM(A, B, 0, 1) EVC_PC_TERM(A, B, 0, 0)
+#define EVC_PC_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define EVC_PC_NEXT(x) x = (x + STAGE == NS * STAGE) ? 0 : x + STAGE
+
+        int soff = 0;                                       // byte offset of the stage being READ
+        EVC_PC_BARRIER();                                   // barrier(0): stages 0 and 1 are published
+        if (nst > 0) { EVC_PC_READ(a0, b0, 0) }
+        int t = 0;
+        for (; t + 1 < nst; t += 2) {
+            EVC_PC_NEXT(soff);
+            EVC_PC_READ(a1, b1, soff)                       // fragments of step t+1 while the MFMAs of step t run
+            __builtin_amdgcn_sched_barrier(0);              // (keep the reads up here: the scheduler would sink them)
+            EVC_PC_MFMAS(a0, b0)
+            EVC_PC_BARRIER();                               // barrier(t+1)
+            EVC_PC_NEXT(soff);
+            EVC_PC_READ(a0, b0, soff)
+            __builtin_amdgcn_sched_barrier(0);
+            EVC_PC_MFMAS(a1, b1)
+            EVC_PC_BARRIER();                               // barrier(t+2)
+        }
+        if (t < nst) {
+            EVC_PC_MFMAS(a0, b0)
+            EVC_PC_BARRIER();
+        }
+#undef EVC_PC_READ
+#undef EVC_PC_TERM
+#undef EVC_PC_MFMAS
+        __builtin_amdgcn_s_setprio(0);
+        conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
+    } else {
+        // ================================ producer ================================
+        const int pw = wave - 4;
+        const int tid = threadIdx.x - 256;
+        const int row = tid >> 1, kh = tid & 1;
+        const int padH = p.KH >> 1, padW = p.KW >> 1;
+        const int Ct = p.C0 + p.C1;
+        unsigned off0, off1, okmask = 0;
+        int rb;
+        {
+            const int m = m0 + row;
+            const bool valid = m < p.M;
+            const int mm = valid ? m : 0;
+            const int b = mm / p.HW;
+            const int rem = mm - b * p.HW;
+            const int y = rem / p.W;
+            const int x = rem - y * p.W;
+            rb = b;
+            off0 = ((unsigned)mm * (unsigned)p.ld0 + 8u * kh) * 4u;
+            off1 = ((unsigned)mm * (unsigned)p.ld1 + 8u * kh) * 4u;
+            for (int ty = 0; ty < p.KH; ++ty)
+                for (int tx = 0; tx < p.KW; ++tx) {
+                    const int yy = y + ty - padH, xx = x + tx - padW;
+                    const bool ok = valid && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                    okmask |= (ok ? 1u : 0u) << (ty * p.KW + tx);
+                }
+        }
+        const int a_lds = row * RB + 16 * (kh ^ ((row >> 3) & 1));
+        unsigned wsrc[NWD];
+        int wdst[NWD];
+#pragma unroll
+        for (int j = 0; j < NWD; ++j) {
+            const int idx = min(pw + 4 * j, 6 * TN - 1);
+            const int part = idx / (2 * TN), seg = idx - part * (2 * TN);
+            wsrc[j] = (unsigned)((part * p.CoPad + n0 + seg * 32) * RB + lane * 16);
+            wdst[j] = WOFF + (part * BN + seg * 32) * RB;
+        }
+        const unsigned slab = 3u * (unsigned)p.CoPad * RB;
+        const unsigned w_tap = (unsigned)p.nchunk * slab;
+        const unsigned w_wrap = slab - (unsigned)(p.KH * p.KW) * w_tap;
+        int w_ty, w_tx, l_chunk, l_ty, l_tx;
+        {
+            const int taps = p.KH * p.KW;
+            l_chunk = s_begin / taps;
+            const int tap = s_begin - l_chunk * taps;
+            l_ty = w_ty = tap / p.KW;
+            l_tx = w_tx = tap - l_ty * p.KW;
+        }
+        unsigned w_off = (unsigned)((w_ty * p.KW + w_tx) * p.nchunk + l_chunk) * slab;
+        const char* a_src; int a_px, a_delta; unsigned a_safe; bool a_first;
+        auto chunk_setup = [&]() {
+            const int c = l_chunk * KC;
+            a_first = c < p.C0;
+            a_src = reinterpret_cast<const char*>(a_first ? p.src0 : p.src1);
+            a_px = (a_first ? p.ld0 : p.ld1) * 4;
+            const int cc = a_first ? c : c - p.C0;
+            a_delta = ((l_ty - padH) * p.W + (l_tx - padW)) * a_px + cc * 4;
+            a_safe = (unsigned)(cc + 8 * kh) * 4u;
+        };
+        // one staged K-step: raw activations, the GroupNorm coefficients of its chunk, in-image flag
+        struct Staged { float4 v[2], ca[2], cs[2]; bool ok; };
+        Staged s0, s1;
+        auto load_a = [&](Staged& d) {                     // the step L points at; always VOPS - NWD operations
+            if (EVC_CONV_ABLATE & 2) return;
+            d.ok = (okmask >> (l_ty * p.KW + l_tx)) & 1u;
+            const unsigned o = d.ok ? (a_first ? off0 : off1) + (unsigned)a_delta : a_safe;
+            d.v[0] = *reinterpret_cast<const float4*>(a_src + o);
+            d.v[1] = *reinterpret_cast<const float4*>(a_src + o + 16);
+            if (HAS_COEF) {
+                const size_t co = (size_t)rb * Ct + l_chunk * KC + 8 * kh;
+                d.ca[0] = *reinterpret_cast<const float4*>(p.coef_a + co);
+                d.ca[1] = *reinterpret_cast<const float4*>(p.coef_a + co + 4);
+                d.cs[0] = *reinterpret_cast<const float4*>(p.coef_s + co);
+                d.cs[1] = *reinterpret_cast<const float4*>(p.coef_s + co + 4);
+            }
+        };
+        auto dma_w = [&](int soff) {
+            const char* wt = reinterpret_cast<const char*>(p.w) + w_off;
+            char* wl = smem_b + soff;
+#pragma unroll
+            for (int j = 0; j < ((EVC_CONV_ABLATE & 1) ? 0 : NWD); ++j)
+                __builtin_amdgcn_global_load_lds((glb_void*)(wt + wsrc[j]), (lds_void*)(wl + wdst[j]), 16, 0, 0);
+        };
+        auto advance_w = [&]() {
+            ++w_tx; w_off += w_tap;
+            if (w_tx == p.KW) { w_tx = 0; ++w_ty; }
+            if (w_ty == p.KH) { w_ty = 0; w_off += w_wrap; }
+        };
+        auto advance_l = [&]() {
+            ++l_tx; a_delta += a_px;
+            if (l_tx == p.KW) { l_tx = 0; ++l_ty; a_delta += (p.W - p.KW) * a_px; }
+            if (l_ty == p.KH) { l_ty = 0; ++l_chunk; chunk_setup(); }
+        };
+        auto store_a = [&](const Staged& d, int soff) {
+            if (EVC_CONV_ABLATE & 2) return;
+            bf16x8 p1, p2, p3;
+            split3_bf16(transform<MODE>(d.v[0], d.ca[0], d.cs[0], d.ok), transform<MODE>(d.v[1], d.ca[1], d.cs[1], d.ok), p1, p2, p3);
+            char* A = smem_b + soff + a_lds;
+            *reinterpret_cast<bf16x8*>(A) = p1;
+            *reinterpret_cast<bf16x8*>(A + BM * RB) = p2;
+            *reinterpret_cast<bf16x8*>(A + 2 * BM * RB) = p3;
+        };
+
+        // ---- prologue: stages 0 and 1 complete; DMA of stages 2, 3 and the activations of steps 2, 3 in flight ----
+        chunk_setup();
+        load_a(s0); dma_w(0 * STAGE); store_a(s0, 0 * STAGE);
+        if (1 < nst) { advance_l(); advance_w(); }
+        load_a(s0); dma_w(1 * STAGE); store_a(s0, 1 * STAGE);
+        if (2 < nst) { advance_l(); advance_w(); }
+        load_a(s0); dma_w(2 * STAGE);
+        if (3 < nst) { advance_l(); advance_w(); }
+        load_a(s1); dma_w(3 * STAGE);
+        if (4 < nst) advance_w();
+        int st_store = 2 * STAGE, st_dma = 4 * STAGE;
+        // everything but the two youngest steps' operations has landed
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VWAIT) : "memory");          // barrier(0)
+#define EVC_PC_PROD(SET, T)                                                                                  \
+        dma_w(st_dma);                                      /* weights of step T+4 */                        \
+        if ((T) + 5 < nst) advance_w();                                                                      \
+        store_a(SET, st_store);                             /* activations of step T+2 (loaded 2 steps ago) */ \
+        if ((T) + 4 < nst) advance_l();                                                                      \
+        load_a(SET);                                        /* activations of step T+4 */                    \
+        EVC_PC_NEXT(st_store); EVC_PC_NEXT(st_dma);                                                          \
+        /* DMA of step T+2 (issued two iterations ago) has landed; the two youngest iterations stay in flight */ \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VWAIT) : "memory");   /* barrier(T+1) */
+        int t = 0;
+        for (; t + 1 < nst; t += 2) {
+            EVC_PC_PROD(s0, t)
+            EVC_PC_PROD(s1, t + 1)
+        }
+        if (t < nst) { EVC_PC_PROD(s0, t) }
+#undef EVC_PC_PROD
+    }
+#undef EVC_PC_NEXT
+#undef EVC_PC_BARRIER
+}
+#endif  // EVC_SPLIT_PC
 
 #if EVC_CONV_PC
 // Producer / consumer specialisation of the same tiling (128 x 64*TN tile, TM = 2).  A workgroup has 8 waves:
@@ -1499,6 +1751,29 @@ static void launch_split(int mode, dim3 grid, size_t lds, hipStream_t st, const 
     }
 }
 
+#if EVC_SPLIT_PC
+template <int TN, int MODE>
+static void launch_split_pc_one(dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+    static bool attr_set = false;      // init-once: allow > 64 KB of dynamic LDS for this instantiation
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_pc_kernel<TN, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_split_pc_kernel<TN, MODE>), grid, dim3(512), lds, st, k);
+}
+template <int TN>
+static void launch_split_pc(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+    switch (mode) {
+        case MODE_AFFINE: launch_split_pc_one<TN, MODE_AFFINE>(grid, lds, st, k); break;
+        case MODE_AFFINE_SILU: launch_split_pc_one<TN, MODE_AFFINE_SILU>(grid, lds, st, k); break;
+        case MODE_SILU: launch_split_pc_one<TN, MODE_SILU>(grid, lds, st, k); break;
+        case MODE_RELU: launch_split_pc_one<TN, MODE_RELU>(grid, lds, st, k); break;
+        default: launch_split_pc_one<TN, MODE_PLAIN>(grid, lds, st, k); break;
+    }
+}
+#endif
+
 #if EVC_CONV_PC
 template <int TN>
 static void launch_pc(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
@@ -1564,6 +1839,14 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     hipStream_t st = (hipStream_t)stream;
     if (a->arith == EVC_ARITH_BF16X6) {
         const size_t lds = (size_t)2 * 3 * (cfg.bm + cfg.bn) * 32;
+#if EVC_SPLIT_PC
+        if (cfg.tm == 2) {
+            const size_t lds_pc = (size_t)5 * 3 * (cfg.bm + cfg.bn) * 32;
+            if (cfg.tn == 3) launch_split_pc<3>(mode, grid, lds_pc, st, k);
+            else if (cfg.tn == 2) launch_split_pc<2>(mode, grid, lds_pc, st, k);
+            else launch_split_pc<1>(mode, grid, lds_pc, st, k);
+        } else
+#endif
         if (cfg.tm == 2) {
             if (cfg.tn == 3) launch_split<2, 3>(mode, grid, lds, st, k);
             else if (cfg.tn == 2) launch_split<2, 2>(mode, grid, lds, st, k);
