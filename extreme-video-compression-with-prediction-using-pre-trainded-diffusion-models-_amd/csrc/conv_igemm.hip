@@ -58,11 +58,17 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #define EVC_SPLIT_PIPE 1       // bf16x6 kernel: 1 = software-pipelined schedule (mid-step barrier, fills two steps ahead,
                                // fragment prefetch), 0 = the simple schedule of conv_igemm_kernel (kept for A/B)
 #endif
+#ifndef EVC_SPLIT_ROWREUSE
+#define EVC_SPLIT_ROWREUSE 1   // bf16x6: 3x3 filters on row-aligned 128-pixel tiles stage the activation once per kernel row
+#endif
 #ifndef EVC_SPLIT_PC
 #define EVC_SPLIT_PC 0         // bf16x6: 128-pixel tiles run on the producer/consumer kernel (8 waves, 1 workgroup per CU)
 #endif
 #ifndef EVC_PC_CONSUMER_PRIO
 #define EVC_PC_CONSUMER_PRIO 3
+#endif
+#ifndef EVC_SPLIT_XCD_REMAP
+#define EVC_SPLIT_XCD_REMAP 0     // XCD-contiguous pixel tiles: measured neutral (+-2 %) on MI355X, kept as an option
 #endif
 #ifndef EVC_SPLIT_INTERLEAVE
 #define EVC_SPLIT_INTERLEAVE 5     // bf16x6 kernel: VALU instructions scheduled per MFMA in the second half (0 = compiler's order)
@@ -642,7 +648,20 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
 
-    const int m0 = blockIdx.x * BM;
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD a CONTIGUOUS range of
+    // pixel tiles, so the halo rows neighbouring tiles share are fetched into one L2 instead of eight (bijective
+    // for any tile count: XCD x owns q + (x < r) tiles starting at x*q + min(x, r)).
+#if EVC_SPLIT_XCD_REMAP
+    int mtile;
+    {
+        const int nwg = gridDim.x, x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        mtile = x * q + min(x, r) + i;
+    }
+#else
+    const int mtile = blockIdx.x;
+#endif
+    const int m0 = mtile * BM;
     const int n0 = blockIdx.y * BN;
     const int split = blockIdx.z;
     const int s_begin = split * p.steps_per_split;
@@ -861,6 +880,238 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
     conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
 }
 #endif  // EVC_SPLIT_PIPE
+
+#if EVC_SPLIT_ROWREUSE
+// ---------------------------------------------------------------------------------------------------------------
+// Row-reuse form of the bf16x6 convolution for 3x3 filters on tiles made of whole image rows (128 % W == 0).
+//
+// Under a dense bf16 MFMA load the chip is power-limited (it holds ~1.98 GHz; removing stalls returns only partly as
+// wall time), so what pays is LESS WORK per MFMA.  conv_split_kernel stages every activation element once per
+// filter TAP: 9 gathers, 9 GroupNorm+SiLU evaluations, 9 exact bf16 splits, 9 LDS writes.  Here a macro-step is one
+// (channel chunk, kernel row ty): the 128 pixels of input row y+ty-1 are staged ONCE -- each image row with a zero
+// halo pixel on both sides, so the horizontal borders need no masking -- and the three horizontal taps tx = 0, 1, 2
+// are three K-steps whose A fragments are read from that one image at row offsets shifted by tx (the XOR swizzle
+// stays conflict-free under the shift for W >= 32; 2-way at W = 16, 3-way at W = 8).  Weights still arrive per
+// tap by LDS-DMA.  Activation loads, transform + split arithmetic and LDS writes per MFMA: one third.
+// LDS: 2 x 3 planes x (128/W)(W+2) rows x 32 B for the activations + 2 x 3 x BN x 32 B for the weights (61-68 KB).
+template <int TN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_split_rr_kernel(ConvK p) {
+    constexpr int TM = 2;
+    constexpr int BM = 128;
+    constexpr int BN = 64 * TN;
+    constexpr int RB = 32;
+    constexpr int NWD = (6 * TN + 3) / 4;
+    constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    const int SR = (BM / p.W) * (p.W + 2);            // staged rows: every image row of the tile + 2 halo pixels
+    const int APL = SR * RB;                          // bytes per activation plane
+    char* const As = smem_b;                          // [2][3][SR][32 B]
+    char* const Ws = smem_b + 2 * 3 * APL;            // [2][3][BN][32 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int split = blockIdx.z;
+    const int s_begin = split * p.steps_per_split;                              // multiple of 3 (host)
+    const int nst = min(p.nsteps, s_begin + p.steps_per_split) - s_begin;       // multiple of 3
+    const int nmac = nst / 3;
+
+    // ---- staging thread: pixel row tid/2 of the tile, channel half kh ----
+    const int row = tid >> 1, kh = tid & 1;
+    const int Ct = p.C0 + p.C1;
+    unsigned off0, off1, okrow = 0;
+    int rb;
+    {
+        const int m = m0 + row;
+        const bool valid = m < p.M;
+        const int mm = valid ? m : 0;
+        const int b = mm / p.HW;
+        const int rem = mm - b * p.HW;
+        const int y = rem / p.W;
+        rb = b;
+        off0 = ((unsigned)mm * (unsigned)p.ld0 + 8u * kh) * 4u;
+        off1 = ((unsigned)mm * (unsigned)p.ld1 + 8u * kh) * 4u;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+            const int yy = y + ty - 1;
+            okrow |= ((valid && yy >= 0 && yy < p.H) ? 1u : 0u) << ty;
+        }
+    }
+    const int srow_p = row + 2 * (row / p.W) + 1;                     // staged row of this pixel (dx = 0)
+    const int a_lds = srow_p * RB + 16 * (kh ^ ((srow_p >> 3) & 1));
+    // ---- fragment read offsets: pixel m of the tile at horizontal tap tx sits in staged row m + 2*(m/W) + tx ----
+    int ard[TM][3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = wm * 32 * TM + i * 32 + l31;
+        const int base = ml + 2 * (ml / p.W);
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+            const int sr = base + tx;
+            ard[i][tx] = sr * RB + 16 * (half ^ ((sr >> 3) & 1));
+        }
+    }
+    const int w_rd = wn * 32 * TN * RB + l31 * RB + 16 * (half ^ ((l31 >> 3) & 1));
+
+    unsigned wsrc[NWD];
+    int wdst[NWD];
+#pragma unroll
+    for (int j = 0; j < NWD; ++j) {
+        const int idx = min(wave + 4 * j, 6 * TN - 1);
+        const int part = idx / (2 * TN), seg = idx - part * (2 * TN);
+        wsrc[j] = (unsigned)((part * p.CoPad + n0 + seg * 32) * RB + lane * 16);
+        wdst[j] = (part * BN + seg * 32) * RB;
+    }
+    const unsigned slab = 3u * (unsigned)p.CoPad * RB;
+    const unsigned w_tap = (unsigned)p.nchunk * slab;
+    const unsigned w_wrap = slab - 9u * w_tap;
+
+    // ---- cursors: W over K-steps (tap inner), L over macro-steps (chunk, ty) ----
+    int l_chunk = s_begin / 9;
+    int l_ty = (s_begin - l_chunk * 9) / 3;
+    int w_ty = l_ty, w_tx = 0;
+    unsigned w_off = (unsigned)((w_ty * 3) * p.nchunk + l_chunk) * slab;
+    const char* a_src; int a_rowb, a_delta; bool a_first;
+    unsigned a_safe;
+    auto chunk_setup = [&]() {
+        const int c = l_chunk * KC;
+        a_first = c < p.C0;
+        a_src = reinterpret_cast<const char*>(a_first ? p.src0 : p.src1);
+        a_rowb = (a_first ? p.ld0 : p.ld1) * 4 * p.W;                 // bytes per image row
+        const int cc = a_first ? c : c - p.C0;
+        a_delta = (l_ty - 1) * a_rowb + cc * 4;
+        a_safe = (unsigned)(cc + 8 * kh) * 4u;
+    };
+    float4 areg[2], ca[2], cs[2];
+    bool aok = false;
+    auto load_coefs = [&]() {
+        if (HAS_COEF) {
+            const size_t co = (size_t)rb * Ct + l_chunk * KC + 8 * kh;
+            ca[0] = *reinterpret_cast<const float4*>(p.coef_a + co);
+            ca[1] = *reinterpret_cast<const float4*>(p.coef_a + co + 4);
+            cs[0] = *reinterpret_cast<const float4*>(p.coef_s + co);
+            cs[1] = *reinterpret_cast<const float4*>(p.coef_s + co + 4);
+        }
+    };
+    auto load_a = [&]() {
+        aok = (okrow >> l_ty) & 1u;
+        const unsigned o = aok ? (a_first ? off0 : off1) + (unsigned)a_delta : a_safe;
+        areg[0] = *reinterpret_cast<const float4*>(a_src + o);
+        areg[1] = *reinterpret_cast<const float4*>(a_src + o + 16);
+    };
+    auto advance_l = [&]() {                                           // next macro-step
+        ++l_ty; a_delta += a_rowb;
+        if (l_ty == 3) { l_ty = 0; ++l_chunk; chunk_setup(); load_coefs(); }
+    };
+    auto dma_w = [&](int wb) {
+        const char* wt = reinterpret_cast<const char*>(p.w) + w_off;
+        char* wl = Ws + wb * 3 * BN * RB;
+#pragma unroll
+        for (int j = 0; j < NWD; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void*)(wt + wsrc[j]), (lds_void*)(wl + wdst[j]), 16, 0, 0);
+    };
+    auto advance_w = [&]() {
+        ++w_tx; w_off += w_tap;
+        if (w_tx == 3) { w_tx = 0; ++w_ty; }
+        if (w_ty == 3) { w_ty = 0; w_off += w_wrap; }
+    };
+    auto store_a = [&](int ab) {
+        bf16x8 p1, p2, p3;
+        split3_bf16(transform<MODE>(areg[0], ca[0], cs[0], aok), transform<MODE>(areg[1], ca[1], cs[1], aok), p1, p2, p3);
+        char* A = As + ab * 3 * APL + a_lds;
+        *reinterpret_cast<bf16x8*>(A) = p1;
+        *reinterpret_cast<bf16x8*>(A + APL) = p2;
+        *reinterpret_cast<bf16x8*>(A + 2 * APL) = p3;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // zero both activation images once: the halo pixels stay zero for the whole kernel
+    for (int o = tid * 16; o < 2 * 3 * APL; o += 256 * 16) *reinterpret_cast<float4*>(As + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    if (nmac > 0) {
+        chunk_setup();
+        load_coefs();
+        load_a();
+        dma_w(0);
+        store_a(0);
+        if (1 < nst) advance_w();
+    }
+    __syncthreads();
+
+    int wb = 0, sidx = 0;        // weight buffer of the current K-step, K-step index inside this split
+#define EVC_RR_TERM(qa, qb)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
+#define EVC_RR_FRAGS(TX)                                                                                \
+    bf16x8 a[TM][3], b[TN][3];                                                                          \
+    {                                                                                                   \
+        const char* Ab = As + ab * 3 * APL;                                                             \
+        const char* Wb = Ws + wb * 3 * BN * RB + w_rd;                                                  \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                 \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
+                a[i][q] = *reinterpret_cast<const bf16x8*>(Ab + q * APL + ard[i][TX]);                  \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
+                b[j][q] = *reinterpret_cast<const bf16x8*>(Wb + (q * BN + j * 32) * RB);                \
+        }                                                                                               \
+    }
+#define EVC_RR_NEXT_W()                                                                                 \
+    dma_w(wb ^ 1);                              /* weights of K-step sidx + 1 */                        \
+    if (sidx + 2 < nst) advance_w();
+
+    for (int g = 0; g < nmac; ++g) {
+        const int ab = g & 1;
+        {   // ---- tx = 0: also start the activation loads of the next macro-step (the two youngest operations) ----
+            EVC_RR_NEXT_W()
+            __builtin_amdgcn_sched_barrier(0);          // the loads below must be issued AFTER the DMA (counted wait)
+            if (g + 1 < nmac) advance_l();
+            load_a();
+            __builtin_amdgcn_sched_barrier(0);
+            EVC_RR_FRAGS(0)
+            EVC_RR_TERM(2, 0) EVC_RR_TERM(1, 1) EVC_RR_TERM(0, 2) EVC_RR_TERM(1, 0) EVC_RR_TERM(0, 1) EVC_RR_TERM(0, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // weight DMA landed, loads stay in flight
+            __builtin_amdgcn_sched_barrier(0);
+            wb ^= 1; ++sidx;
+        }
+        {   // ---- tx = 1 ----
+            EVC_RR_NEXT_W()
+            EVC_RR_FRAGS(1)
+            EVC_RR_TERM(2, 0) EVC_RR_TERM(1, 1) EVC_RR_TERM(0, 2) EVC_RR_TERM(1, 0) EVC_RR_TERM(0, 1) EVC_RR_TERM(0, 0)
+            __syncthreads();
+            wb ^= 1; ++sidx;
+        }
+        {   // ---- tx = 2: stage the next macro-step's activation image among the MFMAs ----
+            EVC_RR_NEXT_W()
+            EVC_RR_FRAGS(2)
+            EVC_RR_TERM(2, 0) EVC_RR_TERM(1, 1) EVC_RR_TERM(0, 2)
+            __builtin_amdgcn_sched_barrier(0);
+            store_a(ab ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            EVC_RR_TERM(1, 0) EVC_RR_TERM(0, 1) EVC_RR_TERM(0, 0)
+            __syncthreads();
+            wb ^= 1; ++sidx;
+        }
+    }
+#undef EVC_RR_TERM
+#undef EVC_RR_FRAGS
+#undef EVC_RR_NEXT_W
+
+    conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
+}
+#endif  // EVC_SPLIT_ROWREUSE
 
 #if EVC_SPLIT_PC
 // ---------------------------------------------------------------------------------------------------------------
@@ -1625,6 +1876,7 @@ static int conv_validate(const evc_conv_args* a) {
 // write + combine traffic and no half-empty tiles (A/B: 8x8 768->768 58 -> 69 TFLOP/s; on mid-size grids such
 // as 32x32 576->576 the smaller tile loses, 92 -> 84, so it is not used there).
 struct TileCfg { int tm, tn, bm, bn; long long tiles; int splits; int reuse; int steps_per_split; };
+static int g_no_reuse = 0;     // same: lets the harness A/B the row-reuse kernel inside one binary
 static int g_force_tm = 0;     // tools/conv_bench.hip (same translation unit) sets this to sweep tile heights; never set in the library
 
 // bf16x6 kernel: 2 workgroups per CU (60 KB LDS each) = 512 slots, and a workgroup's speed is set by its own
@@ -1675,6 +1927,10 @@ static TileCfg conv_tile_cfg(const evc_conv_args* a) {
     c.reuse = 0;
     if (a->arith == EVC_ARITH_BF16X6) {
         split_tile_cfg(a, M, ntile, nsteps, c);
+#if EVC_SPLIT_ROWREUSE
+        // row-reuse kernel: 3x3 filters, 128-pixel tiles made of whole image rows
+        if (!g_no_reuse && a->KH == 3 && a->KW == 3 && c.tm == 2 && a->W >= 4 && 128 % a->W == 0) c.reuse = 1;
+#endif
     } else {
         c.tm = (!EVC_CONV_TM1 || ((M + 127) / 128) * ntile >= 64) ? 2 : 1;
         if (g_force_tm) c.tm = g_force_tm;
@@ -1697,7 +1953,8 @@ static TileCfg conv_tile_cfg(const evc_conv_args* a) {
         if (taps > 1 && a->KH <= 3 && a->KW <= 3 && c.bm % a->W == 0) c.reuse = 1;
 #endif
     }
-    const int unit = c.reuse ? a->KH * a->KW : 1;
+    // splits of the row-reuse kernels cover whole (chunk, kernel row) groups (bf16x6: 3 taps) / whole chunks (f32: 9 taps)
+    const int unit = c.reuse ? (a->arith == EVC_ARITH_BF16X6 ? a->KW : a->KH * a->KW) : 1;
     int sps = (nsteps + c.splits - 1) / c.splits;
     sps = (sps + unit - 1) / unit * unit;
     c.steps_per_split = sps;
@@ -1750,6 +2007,29 @@ static void launch_split(int mode, dim3 grid, size_t lds, hipStream_t st, const 
         default: hipLaunchKernelGGL((conv_split_kernel<TM, TN, MODE_PLAIN>), grid, dim3(256), lds, st, k); break;
     }
 }
+
+#if EVC_SPLIT_ROWREUSE
+template <int TN, int MODE>
+static void launch_split_rr_one(dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+    static bool attr_set = false;      // init-once: up to 68 KB of dynamic LDS (W = 8)
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_rr_kernel<TN, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_split_rr_kernel<TN, MODE>), grid, dim3(256), lds, st, k);
+}
+template <int TN>
+static void launch_split_rr(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+    switch (mode) {
+        case MODE_AFFINE: launch_split_rr_one<TN, MODE_AFFINE>(grid, lds, st, k); break;
+        case MODE_AFFINE_SILU: launch_split_rr_one<TN, MODE_AFFINE_SILU>(grid, lds, st, k); break;
+        case MODE_SILU: launch_split_rr_one<TN, MODE_SILU>(grid, lds, st, k); break;
+        case MODE_RELU: launch_split_rr_one<TN, MODE_RELU>(grid, lds, st, k); break;
+        default: launch_split_rr_one<TN, MODE_PLAIN>(grid, lds, st, k); break;
+    }
+}
+#endif
 
 #if EVC_SPLIT_PC
 template <int TN, int MODE>
@@ -1839,6 +2119,14 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     hipStream_t st = (hipStream_t)stream;
     if (a->arith == EVC_ARITH_BF16X6) {
         const size_t lds = (size_t)2 * 3 * (cfg.bm + cfg.bn) * 32;
+#if EVC_SPLIT_ROWREUSE
+        if (cfg.reuse) {
+            const size_t lds_rr = (size_t)2 * 3 * ((128 / a->W) * (a->W + 2) + cfg.bn) * 32;
+            if (cfg.tn == 3) launch_split_rr<3>(mode, grid, lds_rr, st, k);
+            else if (cfg.tn == 2) launch_split_rr<2>(mode, grid, lds_rr, st, k);
+            else launch_split_rr<1>(mode, grid, lds_rr, st, k);
+        } else
+#endif
 #if EVC_SPLIT_PC
         if (cfg.tm == 2) {
             const size_t lds_pc = (size_t)5 * 3 * (cfg.bm + cfg.bn) * 32;
