@@ -112,6 +112,38 @@ def test_conv_fused_epilogue_moments_match_separate_pass(L, arith):
         assert rel(ca, ca2) < 1e-5 and rel(cs, cs2) < 1e-4
 
 
+@pytest.mark.parametrize("B,H,W,C0,C1,Co,splits", [
+    (3, 8, 8, 32, 16, 192, 0),      # W = 8: a 128-pixel tile spans two images; M = 192 leaves a partial last tile
+    (3, 8, 8, 32, 16, 192, 3),      # same through split-K (splits cover whole kernel rows)
+    (2, 16, 16, 48, 0, 192, 2),     # W = 16: eight image rows per tile
+    (2, 32, 32, 16, 32, 64, 0),     # W = 32, Co = 64 (one 64-wide N tile), concat crossing a chunk boundary
+    (1, 64, 64, 16, 0, 128, 0),     # W = 64: two image rows per tile, 128-wide N tile
+    (1, 128, 128, 16, 16, 192, 0),  # W = 128: one image row per tile
+    (1, 4, 4, 16, 0, 192, 0),       # W = 4: 32 image rows per tile, M = 16 (mostly padding)
+])
+def test_conv3x3_row_reuse_shapes(L, B, H, W, C0, C1, Co, splits):
+    """3x3 convolutions on tiles made of whole image rows run on the row-reuse kernel (activation staged once per
+    kernel row, taps read at shifted LDS offsets, zero halo pixels for the horizontal borders): every image width
+    it supports, tiles spanning images, partial tiles, concat sources, GroupNorm+SiLU on load, split-K."""
+    x0 = rnd(50, B, C0, H, W).cuda()
+    x1 = rnd(51, B, C1, H, W).cuda() if C1 else None
+    C = C0 + C1
+    a, s = (1 + 0.2 * rnd(52, B, C)).cuda(), (0.3 * rnd(53, B, C)).cuda()
+    w = (rnd(54, Co, C, 3, 3) / np.sqrt(9 * C)).cuda()
+    b, res = rnd(55, Co).cuda(), rnd(56, B, Co, H, W).cuda()
+    xin = torch.cat([x0, x1], 1).cpu() if C1 else x0.cpu()
+    ref = (F.conv2d(silu_affine(xin, a.cpu(), s.cpu()), w.cpu(), b.cpu(), padding=1) + res.cpu()) * 0.5
+    out = L.conv2d_nhwc(nhwc(x0), L.conv_pack_weights(w, L.ARITH_BF16X6), Co, 3, 3, bias=b,
+                        src1=None if x1 is None else nhwc(x1), coef=(a, s), act_in=L.ACT_SILU, res=nhwc(res),
+                        out_scale=0.5, splits=splits)
+    assert rel(nchw(out), ref) < 1e-5
+    # plain (no transform) input through the same kernel
+    ref2 = F.conv2d(xin, w.cpu(), None, padding=1)
+    out2 = L.conv2d_nhwc(nhwc(x0), L.conv_pack_weights(w, L.ARITH_BF16X6), Co, 3, 3,
+                         src1=None if x1 is None else nhwc(x1), splits=splits)
+    assert rel(nchw(out2), ref2) < 1e-5
+
+
 def test_conv_bf16x6_is_not_less_accurate_than_f32_mfma(L):
     """The precision claim of EVC_ARITH_BF16X6, on the real kernel: against an fp64 reference its error is no larger
     than that of the exact-product f32 MFMA path (both accumulate in fp32), for the dominant layer shape with
