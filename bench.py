@@ -77,7 +77,8 @@ def roofline_leg(net, clips, device):
     dom = max(per, key=lambda k: per[k]["ms"])
     d = per[dom]
     arith = prof[0]["arith"]
-    kname = ("conv_split_kernel" if arith == L.ARITH_BF16X6 else "conv_igemm_kernel") + f"<{dom}>"
+    # bf16x6: 3x3 layers run conv_split_rr_kernel<TN>, 1x1 / unaligned ones conv_split_kernel<2|1, TN>: one family, same tile
+    kname = ("conv_split_rr_kernel|conv_split_kernel" if arith == L.ARITH_BF16X6 else "conv_igemm_kernel") + f"<TN={dom}>"
     peak = BF16X6_PEAK_TFLOPS if arith == L.ARITH_BF16X6 else F32_MFMA_PEAK_TFLOPS
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     total_conv_ms = sum(v["ms"] for v in per.values()) / 3

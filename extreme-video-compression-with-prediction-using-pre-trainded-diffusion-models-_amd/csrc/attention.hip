@@ -18,6 +18,10 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef EVC_ATTN_MIN_WG
+#define EVC_ATTN_MIN_WG 256      // fewest workgroups a launch should offer before the waves per workgroup are halved
+#endif
+
 namespace {
 
 template <int D, int WAVES>
@@ -144,7 +148,7 @@ int launch(const float* q, const float* k, const float* v, int ld, float* out, i
     const size_t lds = (size_t)2 * 32 * (D + 4) * sizeof(float);
     const long long bh = (long long)B * heads;
     int waves = 4;
-    while (waves > 1 && bh * ((N + 32 * waves - 1) / (32 * waves)) < 256) waves >>= 1;
+    while (waves > 1 && bh * ((N + 32 * waves - 1) / (32 * waves)) < EVC_ATTN_MIN_WG) waves >>= 1;
     dim3 grid((N + 32 * waves - 1) / (32 * waves), heads, B);
     if (waves == 4)
         hipLaunchKernelGGL((attention_kernel<D, 4>), grid, dim3(256), lds, st, q, k, v, ld, out, ld_out, N, scale);
