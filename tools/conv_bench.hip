@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
                          {16, 576, 576, 3}, {16, 768, 768, 3}, {8, 768, 768, 3}, {8, 1536, 768, 3}, {32, 384, 1152, 1},
                          {16, 576, 1728, 1}, {8, 768, 2304, 1}, {8, 768, 768, 1}, {16, 576, 576, 1}};
         const int Bs[] = {9, 5, 4};
-        const int sp[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
+        const int sp[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 24};
         for (const S2& q : ss) for (int B : Bs) {
             const size_t nx = (size_t)B * q.R * q.R * q.Ci, no = (size_t)B * q.R * q.R * q.Co, nraw = (size_t)q.Co * q.Ci * q.K * q.K;
             float *x, *wraw, *o, *ca, *cs; void* wp;
@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
             const int def_splits = evc_conv_choose_splits(&a);
             const int def_tm = conv_tile_cfg(&a).tm;
             double best = 0, deftf = 0; int btm = 0, bsp = 0;
-            char line[1024]; int off = 0;
+            char line[2048]; int off = 0;
             for (int tm = 1; tm <= 2; ++tm) for (int spi : sp) {
                 g_force_tm = tm; a.splits = spi;
                 if ((long long)spi * no * 4 > ((long long)1 << 31)) continue;
