@@ -914,7 +914,17 @@ __global__ __launch_bounds__(256, 2) void conv_split_rr_kernel(ConvK p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
 
-    const int m0 = blockIdx.x * BM;
+#if EVC_SPLIT_XCD_REMAP      // XCD x owns a contiguous range of pixel tiles (bijective for any tile count)
+    int mtile;
+    {
+        const int nwg = gridDim.x, x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        mtile = x * q + min(x, r) + i;
+    }
+#else
+    const int mtile = blockIdx.x;
+#endif
+    const int m0 = mtile * BM;
     const int n0 = blockIdx.y * BN;
     const int split = blockIdx.z;
     const int s_begin = split * p.steps_per_split;                              // multiple of 3 (host)
