@@ -190,7 +190,8 @@ def main():
            "arithmetic": ("fp32 in / fp32 accumulate; conv products as 6 bf16 MFMAs on an exact 3-way bf16 split of both "
                           "operands (error vs fp64 <= the f32-MFMA path, tests/test_gpu_ops.py)"
                           if L.default_arith() == L.ARITH_BF16X6 else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
-           "config": {"workload": f"configs[1]: {a.clips} clips/GPU x 30 frames 128x128, q3, 2 ELIC key frames + "
+           "config": {"workload": f"{'configs[1]' if (a.clips, a.sampler, a.subsample) == (9, 'DDPM', 100) else 'custom'}: "
+                                  f"{a.clips} clips/GPU x 30 frames 128x128, q3, 2 ELIC key frames + "
                                   f"6 chunks x {fwd_per_chunk} forwards ({a.sampler}-{a.subsample}), B={a.clips} per launch",
                       "parallelism": f"clip-sharded dp{world}, no data-path collective; {a.groups} concurrent clip "
                                      f"group(s) per GPU",

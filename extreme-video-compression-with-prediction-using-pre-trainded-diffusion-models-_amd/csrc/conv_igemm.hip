@@ -61,6 +61,9 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #ifndef EVC_SPLIT_ROWREUSE
 #define EVC_SPLIT_ROWREUSE 1   // bf16x6: 3x3 filters on row-aligned 128-pixel tiles stage the activation once per kernel row
 #endif
+#ifndef EVC_SPLIT_WIDE_TILES
+#define EVC_SPLIT_WIDE_TILES 1
+#endif
 #ifndef EVC_SPLIT_PC
 #define EVC_SPLIT_PC 0         // bf16x6: 128-pixel tiles run on the producer/consumer kernel (8 waves, 1 workgroup per CU)
 #endif
@@ -139,10 +142,10 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[TM][TN], const float4 (
 // Epilogue shared by the convolution kernels.  C/D map of the 32x32 MFMA: col = lane & 31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Fuses bias + residual + scale + activation and, for full tiles, the
 // per-channel GroupNorm moments of the output; split-K launches write raw partial sums to their slab instead.
-template <int TM, int TN>
+template <int TM, int TN, int WM = 2>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][TN], int m0, int n0, int split,
                                               int wm, int wn, int l31, int half) {
-    constexpr int BM = 64 * TM;
+    constexpr int BM = 32 * TM * WM;       // WM = waves along the pixel dimension (2, or 4 in the 8-wave row-reuse kernel)
     constexpr int BN = 64 * TN;
     const bool partial = p.splits > 1;
     const int mw = m0 + wm * 32 * TM + 4 * half;
@@ -894,13 +897,17 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
 // stays conflict-free under the shift for W >= 32; 2-way at W = 16, 3-way at W = 8).  Weights still arrive per
 // tap by LDS-DMA.  Activation loads, transform + split arithmetic and LDS writes per MFMA: one third.
 // LDS: 2 x 3 planes x (128/W)(W+2) rows x 32 B for the activations + 2 x 3 x BN x 32 B for the weights (61-68 KB).
-template <int TN, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_split_rr_kernel(ConvK p) {
+// WM = 2: 128-pixel tile, 4 waves, 2 workgroups per CU.  WM = 4: 256-pixel tile, 8 waves, 1 workgroup per CU -- the
+// weight slab is shared by twice the MFMAs (weight DMA per MFMA halved; it costs ~12 % at WM = 2); used for grids
+// that still offer >= 2 rounds of 256-pixel tiles.
+template <int WM, int TN, int MODE>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kernel(ConvK p) {
     constexpr int TM = 2;
-    constexpr int BM = 128;
+    constexpr int BM = 64 * WM;
+    constexpr int NT = 128 * WM;
     constexpr int BN = 64 * TN;
     constexpr int RB = 32;
-    constexpr int NWD = (6 * TN + 3) / 4;
+    constexpr int NWD = WM == 2 ? (6 * TN + 3) / 4 : TN;        // WM = 4: waves 0..5 move TN pieces each (6*TN in all)
     constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     const int SR = (BM / p.W) * (p.W + 2);            // staged rows: every image row of the tile + 2 halo pixels
@@ -970,9 +977,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_rr_kernel(ConvK p) {
 
     unsigned wsrc[NWD];
     int wdst[NWD];
+    const bool w_active = WM == 2 || wave < 6;                         // wave-uniform
 #pragma unroll
     for (int j = 0; j < NWD; ++j) {
-        const int idx = min(wave + 4 * j, 6 * TN - 1);
+        const int idx = WM == 2 ? min(wave + 4 * j, 6 * TN - 1) : min(wave * TN + j, 6 * TN - 1);
         const int part = idx / (2 * TN), seg = idx - part * (2 * TN);
         wsrc[j] = (unsigned)((part * p.CoPad + n0 + seg * 32) * RB + lane * 16);
         wdst[j] = (part * BN + seg * 32) * RB;
@@ -1021,9 +1029,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_rr_kernel(ConvK p) {
     auto dma_w = [&](int wb) {
         const char* wt = reinterpret_cast<const char*>(p.w) + w_off;
         char* wl = Ws + wb * 3 * BN * RB;
+        if (w_active) {
 #pragma unroll
-        for (int j = 0; j < NWD; ++j)
-            __builtin_amdgcn_global_load_lds((glb_void*)(wt + wsrc[j]), (lds_void*)(wl + wdst[j]), 16, 0, 0);
+            for (int j = 0; j < ((EVC_CONV_ABLATE & 1) ? 0 : NWD); ++j)
+                __builtin_amdgcn_global_load_lds((glb_void*)(wt + wsrc[j]), (lds_void*)(wl + wdst[j]), 16, 0, 0);
+        }
     };
     auto advance_w = [&]() {
         ++w_tx; w_off += w_tap;
@@ -1048,7 +1058,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_rr_kernel(ConvK p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // zero both activation images once: the halo pixels stay zero for the whole kernel
-    for (int o = tid * 16; o < 2 * 3 * APL; o += 256 * 16) *reinterpret_cast<float4*>(As + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int o = tid * 16; o < 2 * 3 * APL; o += NT * 16) *reinterpret_cast<float4*>(As + o) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
     if (nmac > 0) {
@@ -1119,7 +1129,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_rr_kernel(ConvK p) {
 #undef EVC_RR_FRAGS
 #undef EVC_RR_NEXT_W
 
-    conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
+    conv_epilogue<TM, TN, WM>(p, acc, m0, n0, split, wm, wn, l31, half);
 }
 #endif  // EVC_SPLIT_ROWREUSE
 
@@ -1886,6 +1896,7 @@ static int conv_validate(const evc_conv_args* a) {
 // write + combine traffic and no half-empty tiles (A/B: 8x8 768->768 58 -> 69 TFLOP/s; on mid-size grids such
 // as 32x32 576->576 the smaller tile loses, 92 -> 84, so it is not used there).
 struct TileCfg { int tm, tn, bm, bn; long long tiles; int splits; int reuse; int steps_per_split; };
+static int g_wide_tiles = EVC_SPLIT_WIDE_TILES;   // harness A/B switch for the 256-pixel row-reuse tiles
 static int g_no_reuse = 0;     // same: lets the harness A/B the row-reuse kernel inside one binary
 static int g_force_tm = 0;     // tools/conv_bench.hip (same translation unit) sets this to sweep tile heights; never set in the library
 
@@ -1940,6 +1951,16 @@ static TileCfg conv_tile_cfg(const evc_conv_args* a) {
 #if EVC_SPLIT_ROWREUSE
         // row-reuse kernel: 3x3 filters, 128-pixel tiles made of whole image rows
         if (!g_no_reuse && a->KH == 3 && a->KW == 3 && c.tm == 2 && a->W >= 4 && 128 % a->W == 0) c.reuse = 1;
+        // 8-wave / 256-pixel form of the row-reuse kernel (one workgroup per CU = 256 slots).  Measured (B=8, 128x128:
+        // exactly 2 rounds) +4-5 %; at B=9 (2.25 rounds) -5 %: the coarser tile makes the tail worse.  So: unsplit
+        // grids that are a whole number of >= 2 rounds, or long enough (>= 6 rounds) for the tail not to matter.
+        if (c.reuse && c.splits == 1 && g_wide_tiles && M % 256 == 0) {
+            const long long t256 = (M / 256) * ntile;
+            if ((t256 >= 512 && t256 % 256 == 0) || t256 >= 6 * 256) {
+                c.bm = 256;
+                c.tiles = t256;
+            }
+        }
 #endif
     } else {
         c.tm = (!EVC_CONV_TM1 || ((M + 127) / 128) * ntile >= 64) ? 2 : 1;
@@ -2019,24 +2040,24 @@ static void launch_split(int mode, dim3 grid, size_t lds, hipStream_t st, const 
 }
 
 #if EVC_SPLIT_ROWREUSE
-template <int TN, int MODE>
+template <int WM, int TN, int MODE>
 static void launch_split_rr_one(dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
-    static bool attr_set = false;      // init-once: up to 68 KB of dynamic LDS (W = 8)
+    static bool attr_set = false;      // init-once: up to 68 KB (WM = 2, W = 8) / 96 KB (WM = 4) of dynamic LDS
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_rr_kernel<TN, MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_rr_kernel<WM, TN, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (WM == 2 ? 72 : 104) * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_split_rr_kernel<TN, MODE>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((conv_split_rr_kernel<WM, TN, MODE>), grid, dim3(128 * WM), lds, st, k);
 }
-template <int TN>
+template <int WM, int TN>
 static void launch_split_rr(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
     switch (mode) {
-        case MODE_AFFINE: launch_split_rr_one<TN, MODE_AFFINE>(grid, lds, st, k); break;
-        case MODE_AFFINE_SILU: launch_split_rr_one<TN, MODE_AFFINE_SILU>(grid, lds, st, k); break;
-        case MODE_SILU: launch_split_rr_one<TN, MODE_SILU>(grid, lds, st, k); break;
-        case MODE_RELU: launch_split_rr_one<TN, MODE_RELU>(grid, lds, st, k); break;
-        default: launch_split_rr_one<TN, MODE_PLAIN>(grid, lds, st, k); break;
+        case MODE_AFFINE: launch_split_rr_one<WM, TN, MODE_AFFINE>(grid, lds, st, k); break;
+        case MODE_AFFINE_SILU: launch_split_rr_one<WM, TN, MODE_AFFINE_SILU>(grid, lds, st, k); break;
+        case MODE_SILU: launch_split_rr_one<WM, TN, MODE_SILU>(grid, lds, st, k); break;
+        case MODE_RELU: launch_split_rr_one<WM, TN, MODE_RELU>(grid, lds, st, k); break;
+        default: launch_split_rr_one<WM, TN, MODE_PLAIN>(grid, lds, st, k); break;
     }
 }
 #endif
@@ -2131,10 +2152,16 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
         const size_t lds = (size_t)2 * 3 * (cfg.bm + cfg.bn) * 32;
 #if EVC_SPLIT_ROWREUSE
         if (cfg.reuse) {
-            const size_t lds_rr = (size_t)2 * 3 * ((128 / a->W) * (a->W + 2) + cfg.bn) * 32;
-            if (cfg.tn == 3) launch_split_rr<3>(mode, grid, lds_rr, st, k);
-            else if (cfg.tn == 2) launch_split_rr<2>(mode, grid, lds_rr, st, k);
-            else launch_split_rr<1>(mode, grid, lds_rr, st, k);
+            const size_t lds_rr = (size_t)2 * 3 * ((cfg.bm / a->W) * (a->W + 2) + cfg.bn) * 32;
+            if (cfg.bm == 256) {
+                if (cfg.tn == 3) launch_split_rr<4, 3>(mode, grid, lds_rr, st, k);
+                else if (cfg.tn == 2) launch_split_rr<4, 2>(mode, grid, lds_rr, st, k);
+                else launch_split_rr<4, 1>(mode, grid, lds_rr, st, k);
+            } else {
+                if (cfg.tn == 3) launch_split_rr<2, 3>(mode, grid, lds_rr, st, k);
+                else if (cfg.tn == 2) launch_split_rr<2, 2>(mode, grid, lds_rr, st, k);
+                else launch_split_rr<2, 1>(mode, grid, lds_rr, st, k);
+            }
         } else
 #endif
 #if EVC_SPLIT_PC

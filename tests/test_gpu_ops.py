@@ -120,6 +120,7 @@ def test_conv_fused_epilogue_moments_match_separate_pass(L, arith):
     (1, 64, 64, 16, 0, 128, 0),     # W = 64: two image rows per tile, 128-wide N tile
     (1, 128, 128, 16, 16, 192, 0),  # W = 128: one image row per tile
     (1, 4, 4, 16, 0, 192, 0),       # W = 4: 32 image rows per tile, M = 16 (mostly padding)
+    (8, 128, 128, 16, 16, 64, 0),   # 512 tiles of 256 pixels: the 8-wave / 256-pixel form of the kernel
 ])
 def test_conv3x3_row_reuse_shapes(L, B, H, W, C0, C1, Co, splits):
     """3x3 convolutions on tiles made of whole image rows run on the row-reuse kernel (activation staged once per
