@@ -85,7 +85,12 @@ int evc_gn_coeffs_f32(const float* part0, int nsplit0, int C0, const float* part
 int evc_affine_act_nhwc_f32(const float* x, float* y, const float* coef_a, const float* coef_s, int act, int B,
                             int HW, int C, int ld_coef, int ld_out, void* stream);
 
-/* ---- convolution as implicit GEMM on the f32 matrix cores ----------------------------------
+/* ---- convolution as implicit GEMM on the matrix cores -----------------------------------------
+ * Two arithmetics, both fp32 in / fp32 accumulate (see EVC_ARITH_* above); the packing of the weights selects one:
+ *   EVC_ARITH_BF16X6 (default of the Python host): conv_split_rr_kernel for 3x3 filters on tiles made of whole image
+ *     rows (W divides 128: every 3x3 layer of the score network and of ELIC's 8..128-wide stages), conv_split_kernel
+ *     for everything else (1x1, 5x5, odd widths);
+ *   EVC_ARITH_F32: conv_igemm_kernel (v_mfma_f32_32x32x2_f32).
  * Stride-1 "same" convolution (odd KH x KW, zero padding) over the virtual concat [src0 | src1] of
  * NHWC tensors.  Replaces nn.Conv2d 3x3 / 1x1 (models/better/layers.py:89-113), NIN
  * (models/better/layers.py:535-544), nn.Linear (time-embedding MLP, Dense_0) and the ELIC conv
