@@ -41,13 +41,12 @@ def conv_probe(B):
 
 
 def forward_probe(Bs):
-    from oracle.scorenet import Dims, seeded_params
+    from evc_amd import synthetic
     from evc_amd.config import default_config as make_config
     from evc_amd.scorenet import ScoreNet
-    d = Dims()
     t0 = time.time()
-    p = seeded_params(d, 1234)
-    net = ScoreNet(make_config(192, 192, 128), p)
+    cfg = make_config(192, 192, 128)
+    net = ScoreNet(cfg, synthetic.diffusion_state_dict(cfg, 1234))
     torch.cuda.synchronize()
     print(f"weights built+packed in {time.time() - t0:.1f}s", flush=True)
     for B in Bs:
@@ -68,10 +67,11 @@ def forward_probe(Bs):
 def layer_probe(B):
     """Per conv shape inside a real forward: launches, time, TFLOP/s (HIP events around every conv launch)."""
     import collections
-    from oracle.scorenet import Dims, seeded_params
+    from evc_amd import synthetic
     from evc_amd.config import default_config as make_config
     from evc_amd.scorenet import ScoreNet
-    net = ScoreNet(make_config(192, 192, 128), seeded_params(Dims(), 1234))
+    cfg = make_config(192, 192, 128)
+    net = ScoreNet(cfg, synthetic.diffusion_state_dict(cfg, 1234))
     x, c = torch.randn(B, 15, 128, 128, device="cuda"), torch.randn(B, 6, 128, 128, device="cuda")
     net.forward_label(x, 500, c)
     torch.cuda.synchronize()
