@@ -21,12 +21,12 @@ dur = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        name = "split" if "conv_split_kernel" in k else "f32" if "conv_igemm_kernel" in k else None
+        name = "split_rr" if "conv_split_rr_kernel" in k else "split" if "conv_split_kernel" in k else "f32" if "conv_igemm_kernel" in k else None
         if not name: continue
         a = acc[(name, r["Counter_Name"])]
         a[0] += float(r["Counter_Value"]); a[1] += 1
         d = dur[name]; d[0] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"]); d[1] += 1
-for name, (t, n) in dur.items(): print(f"{name} avg kernel time {t / n / 1e3:.1f} us")
+for name, (t, n) in sorted(dur.items()): print(f"{name} avg kernel time {t / n / 1e3:.1f} us")
 for (name, c), (v, n) in sorted(acc.items()):
     print(f"{name:6s} {c:36s} avg {v / n:16.1f}  (n={n})")
 PY
