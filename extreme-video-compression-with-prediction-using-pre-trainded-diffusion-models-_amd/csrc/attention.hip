@@ -18,6 +18,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef EVC_ATTN_WG_TARGET
+#define EVC_ATTN_WG_TARGET 512      // workgroups a key-split launch should offer (2 per CU)
+#endif
 #ifndef EVC_ATTN_MIN_WG
 #define EVC_ATTN_MIN_WG 256      // fewest workgroups a launch should offer before the waves per workgroup are halved
 #endif
@@ -29,7 +32,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_kernel(const float* _
                                                                   const float* __restrict__ k,
                                                                   const float* __restrict__ v, int ld,
                                                                   float* __restrict__ out, int ld_out, int N,
-                                                                  float scale) {
+                                                                  float scale, int kparts, int tiles_per_part,
+                                                                  float* __restrict__ part_o,
+                                                                  float* __restrict__ part_ml) {
     constexpr int LDK = D + 4;         // padded LDS row: (D+4)*4 bytes is an odd number of 16-B slots
     constexpr int NG = D / 8;          // 8-deep k groups of the QK^T product
     constexpr int DT = D / 32;         // 32-wide d tiles of the PV product
@@ -41,7 +46,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_kernel(const float* _
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 32 * WAVES + wave * 32;
+    // key split (flash-decoding style): block x = query block * kparts + key part; each part walks its own range of
+    // 32-key tiles and leaves an UNNORMALISED partial (o, running max, running sum) for attention_merge_kernel
+    const int kpart = kparts > 1 ? blockIdx.x % kparts : 0;
+    const int qblk = kparts > 1 ? blockIdx.x / kparts : blockIdx.x;
+    const int k_begin = kpart * tiles_per_part * 32;
+    const int k_end = kparts > 1 ? min(N, k_begin + tiles_per_part * 32) : N;
+    const int q0 = qblk * 32 * WAVES + wave * 32;
     const size_t base = (size_t)b * N * ld + (size_t)h * D;
     const int myq = q0 + l31;
     const bool qvalid = myq < N;
@@ -62,7 +73,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_kernel(const float* _
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    for (int k0 = 0; k0 < N; k0 += 32) {
+    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
         __syncthreads();   // previous tile fully consumed
         // cooperative K/V tile load: 32 rows x D floats each
         for (int i = tid; i < 32 * (D / 4); i += NT) {
@@ -128,6 +139,24 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_kernel(const float* _
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
+    if (kparts > 1) {
+        // partial result: o unnormalised [part][b][n][h*D + d], (m, l) per [part][b][h][n]
+        if (qvalid) {
+            const size_t heads = gridDim.y, B = gridDim.z;
+            float* op = part_o + (((size_t)kpart * B + b) * N + myq) * (heads * D) + (size_t)h * D;
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(op + 32 * t + 8 * g + 4 * half) =
+                        make_float4(o[t][4 * g], o[t][4 * g + 1], o[t][4 * g + 2], o[t][4 * g + 3]);
+            if (half == 0) {
+                float* ml = part_ml + ((((size_t)kpart * B + b) * heads + h) * N + myq) * 2;
+                ml[0] = m_run; ml[1] = l_tot;
+            }
+        }
+        return;
+    }
     const float inv = 1.0f / l_tot;
     if (qvalid) {
         float* op = out + ((size_t)b * N + myq) * ld_out + (size_t)h * D;
@@ -142,35 +171,128 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_kernel(const float* _
     }
 }
 
+// out[b][n][h*D + d] = sum_p w_p * o_p[d] / sum_p w_p * l_p,  w_p = exp(m_p - max_p m_p): the exact online-softmax
+// merge of the key parts (same formula the kernel applies tile by tile).  One thread per (b, n, h, 4 channels).
+__global__ void attention_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                       float* __restrict__ out, int ld_out, int B, int heads, int N, int D,
+                                       int kparts) {
+    const int D4 = D >> 2;
+    const size_t total = (size_t)B * N * heads * D4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d4 = (int)(i % D4);
+        size_t t = i / D4;
+        const int h = (int)(t % heads); t /= heads;
+        const int n = (int)(t % N);
+        const int b = (int)(t / N);
+        float m = -INFINITY;
+        for (int p = 0; p < kparts; ++p) m = fmaxf(m, part_ml[((((size_t)p * B + b) * heads + h) * N + n) * 2]);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float l = 0.f;
+        for (int p = 0; p < kparts; ++p) {
+            const float* ml = part_ml + ((((size_t)p * B + b) * heads + h) * N + n) * 2;
+            const float w = __expf(ml[0] - m);
+            l += w * ml[1];
+            const float4 v = *reinterpret_cast<const float4*>(part_o + (((size_t)p * B + b) * N + n) * ((size_t)heads * D) +
+                                                              (size_t)h * D + 4 * d4);
+            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        }
+        const float inv = 1.0f / l;
+        *reinterpret_cast<float4*>(out + ((size_t)b * N + n) * ld_out + (size_t)h * D + 4 * d4) =
+            make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
+}
+
+struct AttnPlan { int waves, kparts, tiles_per_part; };
+
+// Waves per workgroup as before; then, when the launch would leave SIMDs idle (fewer than ~1024 waves) and the key
+// loop is long enough, split the keys so that every wave's serial chain shortens (each part >= 2 tiles).
+AttnPlan attention_plan(int B, int heads, int N, bool have_ws) {
+    AttnPlan p;
+    const long long bh = (long long)B * heads;
+    const int ntiles = (N + 31) / 32;
+    if (!have_ws) {
+        p.waves = 4;
+        while (p.waves > 1 && bh * ((N + 32 * p.waves - 1) / (32 * p.waves)) < EVC_ATTN_MIN_WG) p.waves >>= 1;
+        p.kparts = 1;
+    } else {
+        // (waves per workgroup, key parts) jointly: the largest workgroup (K/V tile shared by more waves, fewer LDS
+        // footprints) and the fewest key parts that still offer EVC_ATTN_WG_TARGET workgroups; failing that, the
+        // combination with the most workgroups.  Every key part keeps at least 2 tiles.
+        long long best = -1;
+        p.waves = 1; p.kparts = 1;
+        bool done = false;
+        for (int w = 4; w >= 1 && !done; w >>= 1)
+            for (int kp = 1; kp <= 4; kp *= 2) {
+                if (kp > 1 && ntiles / kp < 2) break;
+                const long long wgs = bh * ((N + 32 * w - 1) / (32 * w)) * kp;
+                if (wgs >= EVC_ATTN_WG_TARGET) { p.waves = w; p.kparts = kp; done = true; break; }
+                if (wgs > best) { best = wgs; p.waves = w; p.kparts = kp; }
+            }
+    }
+    p.tiles_per_part = (ntiles + p.kparts - 1) / p.kparts;
+    p.kparts = (ntiles + p.tiles_per_part - 1) / p.tiles_per_part;       // no empty parts
+    return p;
+}
+
 template <int D>
 int launch(const float* q, const float* k, const float* v, int ld, float* out, int ld_out, int B, int heads, int N,
-           float scale, hipStream_t st) {
+           float scale, float* ws, hipStream_t st) {
     const size_t lds = (size_t)2 * 32 * (D + 4) * sizeof(float);
-    const long long bh = (long long)B * heads;
-    int waves = 4;
-    while (waves > 1 && bh * ((N + 32 * waves - 1) / (32 * waves)) < EVC_ATTN_MIN_WG) waves >>= 1;
-    dim3 grid((N + 32 * waves - 1) / (32 * waves), heads, B);
+    const AttnPlan pl = attention_plan(B, heads, N, ws != nullptr);
+    const int waves = pl.waves;
+    float* part_o = ws;
+    float* part_ml = ws ? ws + (size_t)pl.kparts * B * N * heads * D : nullptr;
+    dim3 grid(((N + 32 * waves - 1) / (32 * waves)) * pl.kparts, heads, B);
     if (waves == 4)
-        hipLaunchKernelGGL((attention_kernel<D, 4>), grid, dim3(256), lds, st, q, k, v, ld, out, ld_out, N, scale);
+        hipLaunchKernelGGL((attention_kernel<D, 4>), grid, dim3(256), lds, st, q, k, v, ld, out, ld_out, N, scale,
+                           pl.kparts, pl.tiles_per_part, part_o, part_ml);
     else if (waves == 2)
-        hipLaunchKernelGGL((attention_kernel<D, 2>), grid, dim3(128), lds, st, q, k, v, ld, out, ld_out, N, scale);
+        hipLaunchKernelGGL((attention_kernel<D, 2>), grid, dim3(128), lds, st, q, k, v, ld, out, ld_out, N, scale,
+                           pl.kparts, pl.tiles_per_part, part_o, part_ml);
     else
-        hipLaunchKernelGGL((attention_kernel<D, 1>), grid, dim3(64), lds, st, q, k, v, ld, out, ld_out, N, scale);
-    return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
+        hipLaunchKernelGGL((attention_kernel<D, 1>), grid, dim3(64), lds, st, q, k, v, ld, out, ld_out, N, scale,
+                           pl.kparts, pl.tiles_per_part, part_o, part_ml);
+    if (hipGetLastError() != hipSuccess) return EVC_ELAUNCH;
+    if (pl.kparts > 1) {
+        const size_t total = (size_t)B * N * heads * (D / 4);
+        const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        hipLaunchKernelGGL(attention_merge_kernel, dim3(blocks), dim3(256), 0, st, part_o, part_ml, out, ld_out, B, heads, N,
+                           D, pl.kparts);
+        if (hipGetLastError() != hipSuccess) return EVC_ELAUNCH;
+    }
+    return EVC_OK;
 }
 
 }  // namespace
 
-extern "C" int evc_attention_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out,
-                                 int B, int heads, int N, int D, float scale, void* stream) {
+static int attention_dispatch(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out,
+                              int B, int heads, int N, int D, float scale, float* ws, void* stream) {
     if (!q || !k || !v || !out || B <= 0 || heads <= 0 || N <= 0 || ld_qkv < heads * D || ld_out < heads * D)
         return EVC_EINVAL;
     if ((ld_qkv & 3) || (ld_out & 3)) return EVC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     switch (D) {
-        case 192: return launch<192>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, st);
-        case 64: return launch<64>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, st);
-        case 32: return launch<32>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, st);
+        case 192: return launch<192>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, ws, st);
+        case 64: return launch<64>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, ws, st);
+        case 32: return launch<32>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, ws, st);
         default: return EVC_EUNSUPPORTED;
     }
+}
+
+extern "C" int evc_attention_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out,
+                                 int B, int heads, int N, int D, float scale, void* stream) {
+    return attention_dispatch(q, k, v, ld_qkv, out, ld_out, B, heads, N, D, scale, nullptr, stream);
+}
+
+extern "C" long long evc_attention_workspace_bytes(int B, int heads, int N, int D) {
+    if (B <= 0 || heads <= 0 || N <= 0 || D <= 0) return EVC_EINVAL;
+    const AttnPlan pl = attention_plan(B, heads, N, true);
+    if (pl.kparts <= 1) return 0;
+    return (long long)pl.kparts * B * N * heads * ((long long)D + 2) * (long long)sizeof(float);
+}
+
+extern "C" int evc_attention_ws_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out,
+                                    int B, int heads, int N, int D, float scale, float* ws, void* stream) {
+    if (evc_attention_workspace_bytes(B, heads, N, D) > 0 && !ws) return EVC_EINVAL;
+    return attention_dispatch(q, k, v, ld_qkv, out, ld_out, B, heads, N, D, scale, ws, stream);
 }

@@ -79,6 +79,9 @@ HIP_SYMBOLS = {
     "evc_conv2d_nhwc_f32": (c_int, [POINTER(ConvArgs), c_void_p, c_void_p]),
     "evc_attention_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                   c_float, c_void_p]),
+    "evc_attention_workspace_bytes": (c_longlong, [c_int, c_int, c_int, c_int]),
+    "evc_attention_ws_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                     c_float, c_void_p, c_void_p]),
     "evc_ddpm_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong] + [c_float] * 5 + [c_int, c_void_p]),
     "evc_ddim_step_f32": (c_int, [c_void_p, c_void_p, c_longlong] + [c_float] * 4 + [c_int, c_void_p]),
     "evc_axpy_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_void_p]),
@@ -408,8 +411,10 @@ def attention(qkv, C, heads, out=None):
     if out is None:
         out = torch.empty((B, N, C), device=qkv.device, dtype=torch.float32)
     base = qkv.data_ptr()
-    _check(L.evc_attention_f32(c_void_p(base), c_void_p(base + 4 * C), c_void_p(base + 8 * C), ld, fptr(out), C, B,
-                               heads, N, D, float(int(D) ** (-0.5)), stream_ptr()), "evc_attention_f32")
+    nbytes = L.evc_attention_workspace_bytes(B, heads, N, D)
+    ws = _workspace(nbytes, qkv.device) if nbytes > 0 else None      # stream-ordered: shared with the conv workspace
+    _check(L.evc_attention_ws_f32(c_void_p(base), c_void_p(base + 4 * C), c_void_p(base + 8 * C), ld, fptr(out), C, B,
+                                  heads, N, D, float(int(D) ** (-0.5)), ptr(ws), stream_ptr()), "evc_attention_ws_f32")
     return out
 
 

@@ -137,6 +137,13 @@ int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stream);
  * Replaces the two einsums + softmax of AttnBlockpp.forward (models/better/layerspp.py:241-246). */
 int evc_attention_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out, int B,
                       int heads, int N, int D, float scale, void* stream);
+/* The same with a workspace of evc_attention_workspace_bytes() bytes (0 = none needed): launches that would leave
+ * SIMDs idle split the KEY range over several workgroups (each leaves an unnormalised partial + running max / sum)
+ * and a merge kernel applies the exact online-softmax combination.  Results equal evc_attention_f32 up to fp32
+ * rounding of the merge. */
+long long evc_attention_workspace_bytes(int B, int heads, int N, int D);
+int evc_attention_ws_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out, int B,
+                         int heads, int N, int D, float scale, float* ws, void* stream);
 
 /* ---- sampler steps (elementwise, flat over n floats) ---------------------------------------- */
 /* DDPM ancestral step (models/__init__.py:289-330):

@@ -266,6 +266,36 @@ def test_attention_peaked_scores_exercise_the_rescale(L):
     assert rel(out, ref) < 2e-5
 
 
+def test_attention_key_split_matches_single_pass(L):
+    """evc_attention_ws_f32 splits the key range over workgroups when a launch would leave SIMDs idle and merges the
+    partial softmax states; it must agree with the single-pass evc_attention_f32 (and with fp64), including a ragged
+    last key tile and key parts whose maxima differ by a lot."""
+    import ctypes
+    lib = L.hip_lib()
+    for (B, heads, N, D) in ((1, 2, 200, 192), (2, 1, 1024, 64), (9, 2, 1024, 192)):
+        C = heads * D
+        q = rnd(44, B, N, C)
+        k = rnd(45, B, N, C) * torch.linspace(0.3, 4.0, N)[None, :, None]
+        v = rnd(46, B, N, C)
+        qkv = torch.cat([q, k, v], 2).cuda()
+        nbytes = lib.evc_attention_workspace_bytes(B, heads, N, D)
+        assert nbytes > 0                                      # these shapes do split
+        ws = torch.empty(nbytes // 4, device="cuda")
+        out_ws, out_1 = torch.empty(B, N, C, device="cuda"), torch.empty(B, N, C, device="cuda")
+        base = qkv.data_ptr()
+        args = (ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * C), ctypes.c_void_p(base + 8 * C), 3 * C)
+        assert lib.evc_attention_ws_f32(*args, L.fptr(out_ws), C, B, heads, N, D, D ** -0.5, L.ptr(ws), L.stream_ptr()) == 0
+        assert lib.evc_attention_f32(*args, L.fptr(out_1), C, B, heads, N, D, D ** -0.5, L.stream_ptr()) == 0
+        assert rel(out_ws, out_1) < 2e-6
+        if B * N <= 2048:
+            qh, kh, vh = [t.double().reshape(B, N, heads, D).permute(0, 2, 1, 3) for t in (q, k, v)]
+            w = torch.softmax(torch.einsum("bhqd,bhkd->bhqk", qh, kh) * (D ** -0.5), dim=-1)
+            ref = torch.einsum("bhqk,bhkd->bhqd", w, vh).permute(0, 2, 1, 3).reshape(B, N, C).float()
+            assert rel(out_ws, ref) < 2e-5
+    # a workspace is required when the plan splits
+    assert lib.evc_attention_ws_f32(*args, L.fptr(out_ws), C, B, heads, N, D, D ** -0.5, None, L.stream_ptr()) == -1
+
+
 def test_layout_pack_and_unpack(L):
     B, H, W = 2, 6, 10
     x, c = rnd(50, B, 15, H, W).cuda(), rnd(51, B, 6, H, W).cuda()
