@@ -140,7 +140,7 @@ def main(argv=None):
     def report(vid, q, thr, x, gt, bits, d, store):
         bpp = sum(bits) / 128 / 128 / 30
         ps = [cal_psnr(x[i], gt[i]) for i in range(30)]
-        print(f"[rank {rank}] video {vid} q{q} thr {thr:.2f}: d={list(d[:30])} BPP {bpp:.5f} PSNR {np.mean(ps):.3f}",
+        print(f"[rank {rank}] video {vid} q{q} thr {thr:.2f}: d={[int(v) for v in d[:30]]} BPP {bpp:.5f} PSNR {np.mean(ps):.3f}",
               flush=True)
         store.setdefault(vid, ([], []))
         store[vid][0].append(ps); store[vid][1].append(bpp)
