@@ -241,6 +241,23 @@ def test_upfirdn2d_nhwc_with_fused_adagn_silu(L):
     assert torch.equal(nchw(got).cpu(), z)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 32, 16, 12), (1, 192, 8, 8), (3, 48, 4, 4), (1, 16, 32, 64)])
+def test_upfirdn2d_nhwc_fast_paths_with_an_asymmetric_kernel(L, B, C, H, W):
+    """the specialised up-2 / down-2 kernels (4x4 taps, blocks of outputs per thread) against the oracle with a
+    NON-separable, asymmetric kernel (catches flipped or transposed taps), with and without AdaGN+SiLU on load,
+    including sizes where every block touches an image border."""
+    from oracle import upfirdn2d as O
+    x = rnd(33, B, C, H, W).cuda()
+    a, s = (1 + 0.2 * rnd(34, B, C)).cuda(), (0.3 * rnd(35, B, C)).cuda()
+    k = (rnd(36, 4, 4).abs() + 0.1).numpy().astype(np.float32)
+    act = silu_affine(x.cpu(), a.cpu(), s.cpu()).numpy()
+    for src, kw in ((act, dict(coef=(a, s), act=L.ACT_SILU)), (x.cpu().numpy(), {})):
+        got = L.upfirdn2d_nhwc(nhwc(x), k, 2, 1, (2, 1), **kw)
+        np.testing.assert_allclose(nchw(got).cpu().numpy(), O.upfirdn2d(src, k, up=2, down=1, pad=(2, 1)), atol=5e-6)
+        got = L.upfirdn2d_nhwc(nhwc(x), k, 1, 2, (1, 1), **kw)
+        np.testing.assert_allclose(nchw(got).cpu().numpy(), O.upfirdn2d(src, k, up=1, down=2, pad=(1, 1)), atol=5e-6)
+
+
 @pytest.mark.parametrize("B,heads,N,D", [(2, 2, 1024, 192), (1, 4, 64, 192), (2, 3, 256, 192), (2, 2, 96, 32), (1, 1, 64, 64)])
 def test_attention(L, B, heads, N, D):
     C = heads * D
