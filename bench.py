@@ -2,8 +2,12 @@
 """Benchmark of the decode hot path on MI355X: decoded frames/s for 30-frame 128x128 clips at q3.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no torchrun environment the script LAUNCHES the N ranks itself (child processes of
+``python -m torch.distributed.run``, one per GPU, rendezvous on 127.0.0.1) before it makes any HIP call, relays
+rank 0's JSON line and exits with the launcher's status; under an existing torchrun environment
+(``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N``) it is a rank.  A world size
+that differs from ``--gpus`` is an error, never a silent 1-GPU measurement.
 
 One "step" = one pass of the receiver over one batch of clips per GPU (BASELINE.json configs[1]: 9 clips =
 city_bonn[0..8], q3): per clip 2 ELIC key frames are entropy-decoded + synthesised and 28 frames are generated
@@ -12,12 +16,16 @@ forwards per chunk, fp32).  Weak scaling: every GPU decodes its own 9 clips; no 
 (clips are independent); weights are broadcast once from rank 0 over RCCL before timing.
 Synthetic data, seeded random weights of the reference architecture (no checkpoints / dataset offline).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (implicit-GEMM convolution, conv_split_kernel<3> / conv_igemm_kernel<3>): algorithmic
-                  FLOPs per launch / average launch duration measured live with HIP events on the launch stream
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+  roofline     -- the dominant kernel family (implicit-GEMM convolution): algorithmic FLOPs per launch / average launch
+                  duration measured live with HIP events on the launch stream; `traffic` from the committed rocprofv3
+                  PMC passes when (and only when) they were taken on the kernel source that is running
+  hbm_classes  -- achieved HBM rate of the memory-bound kernel classes, HIP-event timed at the
+                  benchmark's shapes
   cpu_baseline -- the CPU oracle (a port, kind "port") timed on this box's host cores on a bounded sample
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,10 +40,20 @@ sys.path.insert(0, REPO)
 FWD_FLOP_PER_SAMPLE = 345_201_475_584      # one score-network forward, one sample
 ELIC_DECODE_FLOP = 10.865e9                # one 128x128 key-frame decode
 F32_MFMA_PEAK_TFLOPS = 157.3               # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix == vector peak
-BF16_MFMA_PEAK_TFLOPS = 2500.0             # same guide: dense bf16 MFMA (no sparsity)
-# EVC_ARITH_BF16X6 issues six bf16 MFMAs per fp32 product (exact 3-way operand split), so the fp32-equivalent roof of
-# that kernel is the bf16 peak / 6; `achieved` stays ALGORITHMIC fp32 FLOPs (2*M*Co*taps*Ci) per second.
-BF16X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+MFMA16_PEAK_TFLOPS = 2500.0                # same guide: dense bf16 / fp16 MFMA (no sparsity)
+HBM_PEAK_GBS = 8000.0
+# fp32-equivalent roofs of the split arithmetics: `achieved` stays ALGORITHMIC fp32 FLOPs (2*M*Co*taps*Ci) per second,
+# the kernel issues 6 (bf16x6) or 3 (f16x3) 16-bit MFMAs per fp32 product.
+ARITH_INFO = {
+    0: ("f32", F32_MFMA_PEAK_TFLOPS, "dense f32 MFMA 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32)"),
+    1: ("bf16x6", MFMA16_PEAK_TFLOPS / 6.0, "dense bf16 MFMA 2500 TFLOP/s / 6 MFMAs per fp32 product (exact 3-way bf16 "
+                                           "split, fp32 accumulate); f32-MFMA roof would be 157.3"),
+    2: ("f16x3", MFMA16_PEAK_TFLOPS / 3.0, "dense fp16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32 product (operands scaled "
+                                          "into range + 2-way fp16 split = 22 significand bits, fp32 accumulate; error vs "
+                                          "fp64 below the f32-MFMA chain, profiles/r02_split_numerics.log); the bf16x6 "
+                                          "roof would be 416.7, the f32-MFMA roof 157.3"),
+}
+CONV_SOURCES = ("extreme-video-compression-with-prediction-using-pre-trainded-diffusion-models-_amd/csrc/conv_igemm.hip",)
 
 
 def parse():
@@ -51,12 +69,23 @@ def parse():
     ap.add_argument("--preactivate", action="store_true",
                     help="apply AdaGN+SiLU once per tensor in its own pass instead of inside the conv operand load")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0,
+                    help="budget of EACH leg of the CPU baseline (all-threads forwards, 1-thread forward)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="run only the multi-rank plumbing (launch, rendezvous, weight-style broadcast, barriers, "
+                         "max-over-ranks) and print the JSON skeleton: works without a GPU (gloo)")
     return ap.parse_args()
 
 
+def source_sha():
+    h = hashlib.sha256()
+    for rel in CONV_SOURCES:
+        h.update(open(os.path.join(REPO, rel), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def roofline_leg(net, clips, device):
-    """One profiled forward at the benchmark batch size: HIP events around every conv launch."""
+    """Profiled forwards at the benchmark batch size: HIP events around every conv launch, on the launch stream."""
     from evc_amd import lib as L
     x = torch.randn(clips, 15, 128, 128, device=device)
     c = torch.randn(clips, 6, 128, 128, device=device)
@@ -64,66 +93,201 @@ def roofline_leg(net, clips, device):
     torch.cuda.synchronize()
     prof = []
     L.CONV_PROFILE = prof
-    for _ in range(3):
+    reps = 3
+    for _ in range(reps):
         net.forward_label(x, 500, c)
     L.CONV_PROFILE = None
     torch.cuda.synchronize()
     per = {}
     for r in prof:
-        v = per.setdefault(r["variant"], dict(n=0, ms=0.0, flops=0.0))
+        v = per.setdefault((r["arith"], r["variant"]), dict(n=0, ms=0.0, flops=0.0))
         v["n"] += 1
         v["ms"] += r["e0"].elapsed_time(r["e1"])
         v["flops"] += r["flops"]
     dom = max(per, key=lambda k: per[k]["ms"])
     d = per[dom]
-    arith = prof[0]["arith"]
-    # bf16x6: 3x3 layers run conv_split_rr_kernel<TN>, 1x1 / unaligned ones conv_split_kernel<2|1, TN>: one family, same tile
-    kname = ("conv_split_rr_kernel|conv_split_kernel" if arith == L.ARITH_BF16X6 else "conv_igemm_kernel") + f"<TN={dom}>"
-    peak = BF16X6_PEAK_TFLOPS if arith == L.ARITH_BF16X6 else F32_MFMA_PEAK_TFLOPS
+    arith, tn = dom
+    name, peak, basis = ARITH_INFO[arith]
+    kname = {0: "conv_igemm_kernel", 1: "conv_split_rr_kernel<3>|conv_split_kernel",
+             2: "conv_split_rr_kernel<2>|conv_splitn_kernel<2>"}[arith] + f"<TN={tn}>"
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-    total_conv_ms = sum(v["ms"] for v in per.values()) / 3
-    traffic = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes (same kernel, same batch)
-    try:
-        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_conv_split_pmc.json" if arith == L.ARITH_BF16X6 else "r01_conv_pmc.json")))
-        if clips == 9 and pmc.get("kernel") == kname:
+    total_ms = sum(v["ms"] for v in per.values()) / reps
+    total_flops = sum(v["flops"] for v in per.values()) / reps
+    traffic, prov = None, "no rocprofv3 PMC profile committed for this kernel source"
+    try:       # HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, only if taken on THIS source
+        pmc = json.load(open(os.path.join(REPO, "profiles", f"r02_conv_{name}_pmc.json")))
+        if pmc.get("source_sha") != source_sha():
+            prov = f"profiles/r02_conv_{name}_pmc.json is stale (taken on source {pmc.get('source_sha')}): not reported"
+        elif clips != pmc.get("batch") or pmc.get("kernel") != kname:
+            prov = f"profiles/r02_conv_{name}_pmc.json covers {pmc.get('kernel')} at B={pmc.get('batch')}"
+        else:
             traffic = pmc["hbm_bytes_per_launch"]
+            prov = f"profiles/r02_conv_{name}_pmc.json, source {pmc['source_sha']}, FETCH_SIZE x2 + WRITE_SIZE"
     except Exception:
         pass
+    by_family = {f"{ARITH_INFO[a][0]}<TN={t}>": {"launches_per_forward": v["n"] // reps,
+                                                 "ms_per_forward": round(v["ms"] / reps, 3),
+                                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
+                 for (a, t), v in sorted(per.items())}
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic,
-            "kernel": kname, "launches_per_forward": d["n"] // 3,
-            "peak_basis": ("dense bf16 MFMA 2500 TFLOP/s / 6 MFMAs per fp32 product (exact 3-way bf16 split, fp32 "
-                           "accumulate); f32-MFMA roof would be 157.3" if arith == L.ARITH_BF16X6
-                           else "dense f32 MFMA 157.3 TFLOP/s"),
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_provenance": prov,
+            "kernel": kname, "launches_per_forward": d["n"] // reps, "peak_basis": basis,
             "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 2),
             "algorithmic_gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 3),
-            "conv_ms_per_forward": round(total_conv_ms, 3), "batch": clips}
+            "achieved_over_f32_mfma_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 3),
+            "conv_ms_per_forward": round(total_ms, 3),
+            "all_conv_tflops": round(total_flops / (total_ms * 1e-3) / 1e12, 2),
+            "families": by_family, "batch": clips}
 
 
-def cpu_baseline_leg(sd, cfg, seconds):
-    """The CPU oracle (oracle/scorenet.py, a port of the reference's PyTorch-CPU path) on this box's host cores.
-    Sample: whole score-network forwards at B=1; frames/s = 5 generated frames / (101 forwards per chunk)."""
-    from oracle import scorenet as ON
+def hbm_classes_leg(clips, device):
+    """achieved HBM rate per memory-bound kernel class = algorithmic bytes (every tensor read / written
+    once) / HIP-event time, at the benchmark's shapes."""
+    from evc_amd import lib as L
+
+    def timeit(fn, iters=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3      # us
+
+    out = {}
+
+    def rep(name, nbytes, us):
+        gbs = nbytes / us / 1e3
+        out[name] = {"GB/s": round(gbs), "frac": round(gbs / HBM_PEAK_GBS, 3), "us": round(us, 1),
+                     "MB": round(nbytes / 1e6, 1)}
+    B = clips
+    k = np.outer([1, 3, 3, 1], [1, 3, 3, 1]).astype(np.float32) / 64
+    x = torch.randn(B, 128, 128, 192, device=device)
+    a, s = torch.rand(B, 192, device=device) + 0.5, torch.randn(B, 192, device=device)
+    n = x.numel() * 4
+    xs = torch.randn(B, 64, 64, 192, device=device)
+    rep("fir_down2_adagn_silu_128to64_c192", n + n // 4,
+        timeit(lambda: L.upfirdn2d_nhwc(x, k, 1, 2, (1, 1), coef=(a, s), act=L.ACT_SILU)))
+    rep("fir_up2_adagn_silu_64to128_c192", xs.numel() * 4 + n,
+        timeit(lambda: L.upfirdn2d_nhwc(xs, k * 4, 2, 1, (2, 1), coef=(a, s), act=L.ACT_SILU)))
+    rep("chan_stats_128_c192", n, timeit(lambda: L.chan_stats(x)))
+    rep("affine_act_128_c192", 2 * n, timeit(lambda: L.affine_act(x, (a, s), L.ACT_SILU)))
+    xt = torch.randn(B, 15, 128, 128, device=device)
+    e, nz = torch.randn_like(xt), torch.randn_like(xt)
+    rep("ddpm_step", 4 * xt.numel() * 4, timeit(lambda: L.ddpm_step(xt, e, nz, 1.0, 0.1, 0.5, 0.5, 0.1, True)))
+    c = torch.randn(B, 6, 128, 128, device=device)
+    rep("pack_nchw_to_nhwc", (21 + 32) * B * 128 * 128 * 4, timeit(lambda: L.pack_nchw_to_nhwc(xt, c, 32)))
+    return out
+
+
+def cpu_baseline_leg(sd_d, sd_e, seconds):
+    """The CPU oracle (oracle/, a port of the reference's PyTorch-CPU path) on this box's host cores.  Bounded sample
+    of the same workload: whole fp32 score-network forwards at B=1 at all threads AND at 1 thread (what the
+    reference CLI runs with: Inference.py:15 sets torch.set_num_threads(1) process-wide), a short DDPM chunk through
+    the oracle sampler (sampler-step cost on top of the forwards), one ELIC key-frame decode."""
+    from oracle import elic as OE, samplers as OS, schedule as OSch, scorenet as ON
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False)
+    except Exception:
+        physical = None
     d = ON.Dims()
-    p = {k: v.cpu() for k, v in sd.items() if k.startswith("unet.all_modules.")}
+    p = {k: v.cpu() for k, v in sd_d.items() if k.startswith("unet.all_modules.")}
     x, c = torch.randn(1, 15, 128, 128), torch.randn(1, 6, 128, 128)
     lab = torch.tensor([500])
-    ON.forward(p, d, x, lab, cond=c)     # warm
-    n, t0 = 0, time.time()
-    while time.time() - t0 < seconds and n < 40:
-        ON.forward(p, d, x, lab, cond=c)
-        n += 1
-    t = (time.time() - t0) / n
-    cores = torch.get_num_threads()
-    return {"value": round(5.0 / (101 * t), 5), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} fp32 score-network forwards (B=1, 345.2 GFLOP each, {t:.3f} s/forward, "
-                      f"torch CPU {cores} threads); generated frames/s = 5/(101*t); ELIC key frames excluded"}
+    # torchrun exports OMP_NUM_THREADS=1 to its ranks: "all threads" means the cores this process may run on
+    n_all = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_before = torch.get_num_threads()
+    torch.set_num_threads(n_all)
+
+    def time_forwards(budget, max_n):
+        ON.forward(p, d, x, lab, cond=c)     # warm
+        n, t0 = 0, time.time()
+        while n < 1 or (time.time() - t0 < budget and n < max_n):
+            ON.forward(p, d, x, lab, cond=c)
+            n += 1
+        return (time.time() - t0) / n, n
+    t_all, n_fwd = time_forwards(seconds, 40)
+    # a 2-step DDPM chunk = 3 forwards + 2 updates + denoise: the per-step sampler cost beside the forwards
+    t0 = time.time()
+    OS.ddpm(x.clone(), lambda xx, t: ON.forward(p, d, xx, t, cond=c), OSch.base_schedule(), subsample_steps=2)
+    t_chunk3 = time.time() - t0
+    step_overhead = max(0.0, (t_chunk3 - 3 * t_all) / 3)
+    chunk_all = 101 * (t_all + step_overhead)
+    torch.set_num_threads(1)
+    try:
+        t_one, n_one = time_forwards(min(seconds, 10.0), 2)
+    finally:
+        torch.set_num_threads(n_all)
+    # one ELIC key-frame decode on the CPU (oracle nets; range coding through the native coder, as compressai's is C++)
+    elic_ms = None
+    try:
+        from evc_amd import lib as L
+
+        class _Coder:
+            encode_with_indexes = staticmethod(L.rans_encode)
+            decode_with_indexes = staticmethod(L.rans_decode)
+        pe = {k: v.cpu() for k, v in sd_e.items()}
+        img = torch.rand(1, 3, 128, 128)
+        enc = OE.compress(pe, img, coder=_Coder)
+        t0 = time.time()
+        OE.decompress(pe, enc["strings"], enc["shape"], coder=_Coder)
+        elic_ms = (time.time() - t0) * 1e3
+    except Exception as ex:       # the baseline must never take the benchmark down
+        elic_ms = f"failed: {type(ex).__name__}: {ex}"
+    torch.set_num_threads(n_before)
+    clip_s = 6 * chunk_all + 2 * (elic_ms / 1e3 if isinstance(elic_ms, float) else 0.0)
+    return {"value": round(30.0 / clip_s, 5), "unit": "frames/s", "cores": n_all, "kind": "port",
+            "physical_cores": physical,
+            "sample": f"{n_fwd} fp32 score-network forwards (B=1, 345.2 GFLOP each) at {n_all} threads: {t_all:.3f} s/forward; "
+                      f"a 2-step DDPM chunk through the oracle sampler: {t_chunk3:.2f} s (sampler step overhead "
+                      f"{step_overhead * 1e3:.0f} ms/step); {n_one} forward(s) at 1 thread: {t_one:.2f} s; one ELIC key-frame "
+                      f"decode: {elic_ms if not isinstance(elic_ms, float) else round(elic_ms, 1)} ms.  value = 30 frames / "
+                      f"(6 chunks x 101 x (forward + step) + 2 key-frame decodes), extrapolated from the sample",
+            "forward_s_all_threads": round(t_all, 4), "forward_s_1_thread": round(t_one, 3),
+            "chunk_s_all_threads": round(chunk_all, 1), "chunk_s_1_thread": round(101 * (t_one + step_overhead), 1),
+            "frames_per_s_1_thread": round(30.0 / (6 * 101 * (t_one + step_overhead)), 6),
+            "elic_keyframe_decode_ms": elic_ms if not isinstance(elic_ms, float) else round(elic_ms, 1),
+            "note": "the reference additionally re-reads its 1 GB checkpoint for every chunk (city_sender.py:337); not "
+                    "included"}
+
+
+def plumbing_only(a, D):
+    """Multi-rank plumbing without the GPU path: what a CPU (gloo) test can assert about `bench.py --gpus N`."""
+    rank, world, device = D.init()
+    if world != a.gpus:
+        print(f"error: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    sd = {"w": torch.arange(1000, dtype=torch.float32)} if rank == 0 else None
+    sd = D.broadcast_state_dict(sd, src=0, device=device, world=world)
+    ok = bool((sd["w"].cpu() == torch.arange(1000, dtype=torch.float32)).all())
+    D.barrier()
+    t0 = time.perf_counter()
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
+    seen = int(D.sum_over_ranks(1, device))
+    if rank == 0:
+        print(json.dumps({"metric": "decoded frames/sec (128x128x30) at q3", "value": None, "unit": "frames/s",
+                          "n_gpus": world, "ranks_seen": seen, "backend": D.backend_name(), "plumbing_only": True,
+                          "broadcast_ok": ok, "barrier_s": elapsed,
+                          "self_launched": os.environ.get("EVC_SELF_LAUNCHED") == "1"}), flush=True)
+    D.barrier()
+    return 0 if ok and seen == world else 1
 
 
 def main():
     a = parse()
-    import evc_amd  # noqa: F401
-    from evc_amd import dist as D, lib as L, sampler as S, synthetic
+    import evc_amd  # noqa: F401   (no HIP call: the library loads lazily)
+    from evc_amd import dist as D
+    if D.needs_self_launch(a.gpus):
+        # parent: never touches the GPU; N child ranks do the work and rank 0 prints the line
+        sys.exit(D.self_launch(os.path.abspath(__file__), sys.argv[1:], a.gpus))
+    if a.plumbing_only:
+        sys.exit(plumbing_only(a, D))
+
+    from evc_amd import lib as L, sampler as S, synthetic
     from evc_amd.config import default_config
     from evc_amd.decoder import ClipDecoder, all_generated_mask
     from evc_amd.elic import ElicModel
@@ -131,8 +295,9 @@ def main():
 
     rank, world, device = D.init()
     if world != a.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+        print(f"error: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {a.gpus} GPUs",
+              file=sys.stderr)
+        sys.exit(2)
     L.hip_lib()
     torch.cuda.set_device(device)
     cfg = default_config(192, 192, 128, subsample=a.subsample)
@@ -170,6 +335,7 @@ def main():
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
     assert frames.shape == (a.clips, 30, 3, 128, 128) and bool(torch.isfinite(frames).all())
+    seen = int(D.sum_over_ranks(1, device))
 
     # how much of a step is ELIC key-frame decoding (latency-bound: 10 host round trips per batch)
     torch.cuda.synchronize()
@@ -184,12 +350,17 @@ def main():
     value = n_frames / elapsed
     fwd_per_chunk = {"DDPM": a.subsample + 1, "DDIM": a.subsample + 1, "FPNDM": 12 + (a.subsample - 3)}[a.sampler]
     flop_per_step_gpu = a.clips * (6 * fwd_per_chunk * FWD_FLOP_PER_SAMPLE + 2 * ELIC_DECODE_FLOP)
+    policy = {L.ARITH_F32: "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere",
+              L.ARITH_BF16X6: "conv products as 6 bf16 MFMAs on an exact 3-way bf16 split of both operands",
+              L.ARITH_F16X3: "convs on normalised inputs (Conv_0/Conv_1/qkv/output conv: 94 % of the FLOPs): operands scaled "
+                             "into fp16 range, 2-way fp16 split, 3 fp16 MFMAs per product; raw residual-stream convs, NIN out "
+                             "projections, ELIC: exact 3-way bf16 split, 6 bf16 MFMAs"}[L.bounded_arith()]
     out = {"metric": "decoded frames/sec (128x128x30) at q3", "value": round(value, 4), "unit": "frames/s",
-           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
+           "n_gpus": world, "ranks_seen": seen, "backend": D.backend_name(),
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "arithmetic": ("fp32 in / fp32 accumulate; conv products as 6 bf16 MFMAs on an exact 3-way bf16 split of both "
-                          "operands (error vs fp64 <= the f32-MFMA path, tests/test_gpu_ops.py)"
-                          if L.default_arith() == L.ARITH_BF16X6 else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
+           "arithmetic": "fp32 in / fp32 accumulate, fp32-equivalent products (error vs fp64 <= the f32-MFMA path, "
+                         "tests/test_gpu_ops.py): " + policy,
            "config": {"workload": f"{'configs[1]' if (a.clips, a.sampler, a.subsample) == (9, 'DDPM', 100) else 'custom'}: "
                                   f"{a.clips} clips/GPU x 30 frames 128x128, q3, 2 ELIC key frames + "
                                   f"6 chunks x {fwd_per_chunk} forwards ({a.sampler}-{a.subsample}), B={a.clips} per launch",
@@ -200,10 +371,8 @@ def main():
            "elic_keyframe_decode_ms_per_step": round(elic_ms, 1)}
     if rank == 0:
         out["roofline"] = roofline_leg(net, a.clips, device)
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_leg(sd_d, cfg, a.cpu_baseline_seconds)
-        else:
-            out["cpu_baseline"] = None
+        out["hbm_classes"] = hbm_classes_leg(a.clips, device)
+        out["cpu_baseline"] = None if a.no_cpu_baseline else cpu_baseline_leg(sd_d, sd_e, a.cpu_baseline_seconds)
     D.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -37,38 +37,11 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #ifndef EVC_CONV_ABLATE
 #define EVC_CONV_ABLATE 0      // DIAGNOSTIC ONLY (wrong results): bit 0 = skip the weight DMA, bit 1 = skip the activation path
 #endif
-#ifndef EVC_CONV_PC
-#define EVC_CONV_PC 0          // 1: 128-pixel tiles run on the producer/consumer-specialised kernel (8 waves)
-#endif
-#ifndef EVC_CONV_PC_OCC
-#define EVC_CONV_PC_OCC 4      // waves per SIMD the producer/consumer kernel is register-budgeted for (2: one 8-wave
-                               // workgroup per CU; 4: two -- 128 VGPRs, spills only outside the main loops)
-#endif
-#ifndef EVC_CONV_ROWREUSE
-#define EVC_CONV_ROWREUSE 0    // 1: 3x3 convs on row-aligned tiles stage the activation once per kernel row instead of once
-                               // per tap (conv_rowreuse_kernel).  Correct (full GPU suite passes with it), but measured on
-                               // MI355X: +4-5 % only for GroupNorm+SiLU convs on full grids at B=8 (103 -> 108 TFLOP/s),
-                               // neutral at B=9, -2..4 % on split-K layers (74 KB LDS -> 2 instead of 3 workgroups per CU),
-                               // so it is compiled out by default.
-#endif
 #ifndef EVC_CONV_TM1
-#define EVC_CONV_TM1 1         // 1: grids with < 64 tiles of 128 pixels use 64-pixel tiles (0 disables, for A/B)
-#endif
-#ifndef EVC_SPLIT_PIPE
-#define EVC_SPLIT_PIPE 1       // bf16x6 kernel: 1 = software-pipelined schedule (mid-step barrier, fills two steps ahead,
-                               // fragment prefetch), 0 = the simple schedule of conv_igemm_kernel (kept for A/B)
-#endif
-#ifndef EVC_SPLIT_ROWREUSE
-#define EVC_SPLIT_ROWREUSE 1   // bf16x6: 3x3 filters on row-aligned 128-pixel tiles stage the activation once per kernel row
+#define EVC_CONV_TM1 1         // f32 kernel: grids with < 64 tiles of 128 pixels use 64-pixel tiles (0 disables, for A/B)
 #endif
 #ifndef EVC_SPLIT_WIDE_TILES
 #define EVC_SPLIT_WIDE_TILES 1
-#endif
-#ifndef EVC_SPLIT_PC
-#define EVC_SPLIT_PC 0         // bf16x6: 128-pixel tiles run on the producer/consumer kernel (8 waves, 1 workgroup per CU)
-#endif
-#ifndef EVC_PC_CONSUMER_PRIO
-#define EVC_PC_CONSUMER_PRIO 3
 #endif
 #ifndef EVC_SPLIT_XCD_REMAP
 #define EVC_SPLIT_XCD_REMAP 0     // XCD-contiguous pixel tiles: measured neutral (+-2 %) on MI355X, kept as an option
@@ -83,6 +56,11 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #define EVC_CONV_PLAIN_DMA 0   // 1: in plain mode the activation tile also goes global -> LDS by DMA (out-of-image lanes
                                // read a zero page). Measured equal to register staging on MI355X; kept as an option.
 #endif
+#ifndef EVC_RR_OCC
+#define EVC_RR_OCC 2           // workgroups per CU the 4-wave row-reuse kernel is register-budgeted for
+#endif
+// (Round-1 variants that measured no gain -- producer/consumer specialised kernels, row reuse on the f32 MFMA -- live in
+//  tools/experiments/conv_variants_r01.hip.inc, outside the product translation unit.)
 
 namespace {
 
@@ -104,6 +82,7 @@ struct ConvK {
     int M, HW, nchunk, nsteps, steps_per_split, splits;
     float* ws;   // split-K slabs [splits][M][Co] when splits > 1
     float* stats;   // optional fused per-channel moments [M/64][Co][2]
+    const float* w_hdr;   // f16x3 only: header of the packed weights, [0] = 1 / (activation scale * weight scale)
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -148,6 +127,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
     constexpr int BM = 32 * TM * WM;       // WM = waves along the pixel dimension (2, or 4 in the 8-wave row-reuse kernel)
     constexpr int BN = 64 * TN;
     const bool partial = p.splits > 1;
+    // f16x3: the operands were scaled by powers of two to sit in fp16's range; undo it here (exact)
+    const float ascale = p.w_hdr ? p.w_hdr[0] : 1.0f;
     const int mw = m0 + wm * 32 * TM + 4 * half;
     const int cw = n0 + wn * 32 * TN + l31;
     if (m0 + BM <= p.M && n0 + BN <= p.Co) {
@@ -163,7 +144,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
                 if (partial) {
                     float* o = p.ws + ((size_t)split * p.M + mb) * p.Co + co;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * p.Co] = acc[i][j][r];
+                    for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * p.Co] = acc[i][j][r] * ascale;
                 } else {
                     float rv[16];
 #pragma unroll
@@ -176,7 +157,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
                     float* o = p.out + (size_t)mb * p.ld_out + co;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float v = act_fn((acc[i][j][r] + bias + rv[r]) * p.out_scale, p.act_out);
+                        const float v = act_fn((acc[i][j][r] * ascale + bias + rv[r]) * p.out_scale, p.act_out);
                         o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ld_out] = v;
                         st_sum += v; st_sq += v * v;
                     }
@@ -205,7 +186,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
                 for (int r = 0; r < 16; ++r) {
                     const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2);
                     if (m >= p.M) continue;
-                    float v = acc[i][j][r];
+                    float v = acc[i][j][r] * ascale;
                     if (partial) {
                         p.ws[((size_t)split * p.M + m) * p.Co + co] = v;
                     } else {
@@ -423,6 +404,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
 // a thread stages 8 channels of one pixel (2 float4 loads -> transform -> split -> 3 ds_write_b128); the weights
 // are split at pack time and arrive by LDS-DMA.  LDS = 192 * (BM + BN) bytes (60 KB at 128 x 192).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split3_bf16(const float4& v0, const float4& v1, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
     const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -435,21 +417,82 @@ __device__ __forceinline__ void split3_bf16(const float4& v0, const float4& v1, 
     }
 }
 
-#if !EVC_SPLIT_PIPE
-template <int TM, int TN, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 on the fp16 matrix cores ("f16x3").  v_mfma_f32_32x32x16_f16 runs at the bf16 rate.  fp16 carries 11
+// significand bits, so a 2-way split  x*S = h1 + h2,  h1 = fp16(x*S), h2 = fp16(x*S - h1)  represents x to 2^-22
+// relative (an fp32 rounding is 2^-24) PROVIDED h2 does not fall into fp16's subnormals: both operands are scaled by
+// powers of two first -- weights by the S_w that brings max|w| into [2^14, 2^15) (per tensor, found at pack time),
+// activations by S_a = 8 (this arithmetic is only used where the operand is GroupNorm-normalised, FIR-filtered or
+// otherwise O(1): |x * S_a| is clamped to 65504 so an outlier saturates instead of turning into inf - inf) -- and the
+// accumulator is multiplied by the exact inverse 1 / (S_a S_w) in the epilogue.  Three products
+//     x*y ~ h1 g1 + h1 g2 + h2 g1              (the dropped h2 g2 is <= 2^-22 |xy|)
+// per 16-deep K slice instead of bf16x6's six: half the MFMAs, two LDS planes per operand instead of three, a cheaper
+// split.  Measured on MI355X against fp64 (tools/split_numerics.hip, profiles/r02_split_numerics.log; SiLU(normal) x
+// normal, K = 1728 / 3456 / 13824): rms error / max|C| 1.12e-7 / 1.52e-7 / 3.44e-7 -- BELOW both the f32 MFMA chain
+// (1.80e-7 / 2.41e-7 / 5.38e-7) and bf16x6 (1.56e-7 / 2.08e-7 / 4.70e-7): with fp32 accumulation the error is
+// dominated by the accumulator roundings, and this scheme does the fewest.  Wide-dynamic-range operands (log-normal
+// scales over e^+-16) do NOT fit fp16's exponent range: raw residual-stream inputs stay on bf16x6 (host's choice,
+// evc_amd/scorenet.py).
+constexpr float F16_ACT_SCALE = 8.0f;
+
+__device__ __forceinline__ void split2_f16(const float4& v0, const float4& v1, f16x8& p1, f16x8& p2) {
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = __builtin_amdgcn_fmed3f(x[j] * F16_ACT_SCALE, -65504.0f, 65504.0f);
+        const _Float16 a = (_Float16)v;
+        p1[j] = a; p2[j] = (_Float16)(v - (float)a);
+    }
+}
+
+// The two split arithmetics share their kernels: NP = planes per operand (3: bf16x6, 2: f16x3).
+template <int NP> struct Split;
+template <> struct Split<3> {
+    typedef bf16x8 vec;
+    static constexpr int NTERM = 6;
+    // cross products, smallest first: (a plane, b plane)
+    static __device__ __forceinline__ constexpr int qa(int t) { return t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0; }
+    static __device__ __forceinline__ constexpr int qb(int t) { return t == 2 ? 2 : (t == 1 || t == 4) ? 1 : 0; }
+    static __device__ __forceinline__ f32x16 mfma(const vec& a, const vec& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void split(const float4& v0, const float4& v1, vec (&pl)[3]) {
+        split3_bf16(v0, v1, pl[0], pl[1], pl[2]);
+    }
+};
+template <> struct Split<2> {
+    typedef f16x8 vec;
+    static constexpr int NTERM = 3;
+    static __device__ __forceinline__ constexpr int qa(int t) { return t == 0 ? 1 : 0; }
+    static __device__ __forceinline__ constexpr int qb(int t) { return t == 1 ? 1 : 0; }
+    static __device__ __forceinline__ f32x16 mfma(const vec& a, const vec& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void split(const float4& v0, const float4& v1, vec (&pl)[2]) {
+        split2_f16(v0, v1, pl[0], pl[1]);
+    }
+};
+
+// Simple schedule (one barrier per K-step, next step's operands fetched during the current one) for any NP; serves
+// f16x3 wherever the row-reuse kernel does not apply (1x1 filters, odd widths).  bf16x6 uses the software-pipelined
+// conv_split_kernel below, whose register juggling is specific to three planes.
+template <int NP, int TM, int TN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_splitn_kernel(ConvK p) {
+    typedef Split<NP> SP;
+    typedef typename SP::vec vec;
     constexpr int BM = 64 * TM;
     constexpr int BN = 64 * TN;
-    constexpr int RB = 32;                       // bytes per LDS row: 16 bf16
-    constexpr int NWD = (6 * TN + 3) / 4;        // weight DMA instructions per wave and K-step
+    constexpr int RB = 32;                             // bytes per LDS row: 16 two-byte elements
+    constexpr int NPIECE = NP * 2 * TN;                // weight DMA pieces of 1 KiB (32 rows of one plane) per K-step
+    constexpr int NWD = (NPIECE + 3) / 4;              // ... per wave
     constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
-    char* const As = smem_b;                          // [2][3][BM][32 B]
-    char* const Ws = smem_b + 2 * 3 * BM * RB;        // [2][3][BN][32 B]
+    char* const As = smem_b;                           // [2][NP][BM][32 B]
+    char* const Ws = smem_b + 2 * NP * BM * RB;        // [2][NP][BN][32 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform by construction: keep it scalar
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
 
@@ -485,28 +528,22 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
             }
     }
     const int a_lds = row * RB + 16 * (kh ^ ((row >> 3) & 1));        // byte offset inside one plane
-    // fragment reads: lane (r = l31, h = half) takes k = 8h .. 8h+7 of row r; tile / wave row offsets are
-    // multiples of 32 rows, so the XOR term depends on the lane only
     const int fr = l31 * RB + 16 * (half ^ ((l31 >> 3) & 1));
     const int a_rd = wm * 32 * TM * RB + fr, w_rd = wn * 32 * TN * RB + fr;
 
-    // ---- weight DMA pieces of this wave (fixed): 6*TN pieces of 1 KiB (32 rows of one plane) over 4 waves; when
-    // that does not divide, the surplus waves of the last round repeat the final piece (identical bytes to the same
-    // place), which keeps the K-step free of branches ----
     unsigned wsrc[NWD];      // per-lane byte offset inside a (tap, chunk) slab
     int wdst[NWD];           // LDS byte offset inside a W buffer (scalar)
 #pragma unroll
     for (int j = 0; j < NWD; ++j) {
-        const int idx = min(wave + 4 * j, 6 * TN - 1);
+        const int idx = min(wave + 4 * j, NPIECE - 1);                // surplus waves repeat the last piece (same bytes)
         const int part = idx / (2 * TN), seg = idx - part * (2 * TN);
         wsrc[j] = (unsigned)((part * p.CoPad + n0 + seg * 32) * RB + lane * 16);
         wdst[j] = (part * BN + seg * 32) * RB;
     }
-    const unsigned slab = 3u * (unsigned)p.CoPad * RB;                 // bytes per (tap, chunk)
+    const unsigned slab = (unsigned)NP * (unsigned)p.CoPad * RB;       // bytes per (tap, chunk)
     const unsigned w_tap = (unsigned)p.nchunk * slab;                  // tap -> tap + 1
     const unsigned w_wrap = slab - (unsigned)(p.KH * p.KW) * w_tap;    // last tap of chunk c -> tap 0 of chunk c + 1
 
-    // ---- "next step" cursor (chunk-major, taps inner) with incrementally maintained scalar offsets ----
     int c_chunk, c_ty, c_tx;
     {
         const int taps = p.KH * p.KW;
@@ -516,11 +553,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
         c_tx = tap - c_ty * p.KW;
     }
     unsigned w_off = (unsigned)((c_ty * p.KW + c_tx) * p.nchunk + c_chunk) * slab;
-    const char* a_src;       // source tensor of the cursor's chunk
-    int a_px;                // bytes per pixel of that source
-    int a_delta;             // byte offset of (tap, chunk) relative to the output pixel's channel 0
-    unsigned a_safe;         // always-legal offset (pixel 0) for out-of-image taps
-    bool a_first;
+    const char* a_src; int a_px, a_delta; unsigned a_safe; bool a_first;
     auto chunk_setup = [&]() {
         const int c = c_chunk * KC;
         a_first = c < p.C0;
@@ -530,9 +563,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
         a_delta = ((c_ty - padH) * p.W + (c_tx - padW)) * a_px + cc * 4;
         a_safe = (unsigned)(cc + 8 * kh) * 4u;
     };
-    float4 areg[2], ca[2], cs[2];
+    float4 areg[2] = {}, ca[2], cs[2];
     bool aok = false;
-
     auto load_coefs = [&]() {
         if (HAS_COEF) {
             const size_t co = (size_t)rb * Ct + c_chunk * KC + 8 * kh;
@@ -550,13 +582,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
             areg[1] = *reinterpret_cast<const float4*>(a_src + o + 16);
         }
         const char* wt = reinterpret_cast<const char*>(p.w) + w_off;
-        char* wl = Ws + buf * 3 * BN * RB;
+        char* wl = Ws + buf * NP * BN * RB;
 #pragma unroll
         for (int j = 0; j < ((EVC_CONV_ABLATE & 1) ? 0 : NWD); ++j)
             __builtin_amdgcn_global_load_lds((glb_void*)(wt + wsrc[j]), (lds_void*)(wl + wdst[j]), 16, 0, 0);
     };
-    // returns true when the cursor moved to a new channel chunk
-    auto advance = [&]() -> bool {
+    auto advance = [&]() -> bool {          // true when the cursor moved to a new channel chunk
         ++c_tx; a_delta += a_px; w_off += w_tap;
         if (c_tx == p.KW) { c_tx = 0; ++c_ty; a_delta += (p.W - p.KW) * a_px; }
         if (c_ty == p.KH) { c_ty = 0; ++c_chunk; w_off += w_wrap; chunk_setup(); return true; }
@@ -564,12 +595,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
     };
     auto store_a = [&](int buf) {
         if (!a_active || (EVC_CONV_ABLATE & 2)) return;
-        bf16x8 p1, p2, p3;
-        split3_bf16(transform<MODE>(areg[0], ca[0], cs[0], aok), transform<MODE>(areg[1], ca[1], cs[1], aok), p1, p2, p3);
-        char* A = As + buf * 3 * BM * RB + a_lds;
-        *reinterpret_cast<bf16x8*>(A) = p1;
-        *reinterpret_cast<bf16x8*>(A + BM * RB) = p2;
-        *reinterpret_cast<bf16x8*>(A + 2 * BM * RB) = p3;
+        vec pl[NP];
+        SP::split(transform<MODE>(areg[0], ca[0], cs[0], aok), transform<MODE>(areg[1], ca[1], cs[1], aok), pl);
+        char* A = As + buf * NP * BM * RB + a_lds;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<vec*>(A + q * BM * RB) = pl[q];
     };
 
     f32x16 acc[TM][TN];
@@ -597,30 +627,33 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
         }
         issue_loads(buf ^ 1);
 
-        const char* Ab = As + buf * 3 * BM * RB + a_rd;
-        const char* Wb = Ws + buf * 3 * BN * RB + w_rd;
-        bf16x8 a[TM][3], b[TN][3];
+        const char* Ab = As + buf * NP * BM * RB + a_rd;
+        const char* Wb = Ws + buf * NP * BN * RB + w_rd;
+        vec a[TM][NP], b[TN][NP];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NP; ++q) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i][q] = *reinterpret_cast<const bf16x8*>(Ab + (q * BM + i * 32) * RB);
+            for (int i = 0; i < TM; ++i) a[i][q] = *reinterpret_cast<const vec*>(Ab + (q * BM + i * 32) * RB);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j][q] = *reinterpret_cast<const bf16x8*>(Wb + (q * BN + j * 32) * RB);
+            for (int j = 0; j < TN; ++j) b[j][q] = *reinterpret_cast<const vec*>(Wb + (q * BN + j * 32) * RB);
         }
-#define EVC_SPLIT_TERM(qa, qb)                                                                          \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)  \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
-        EVC_SPLIT_TERM(2, 0) EVC_SPLIT_TERM(1, 1) EVC_SPLIT_TERM(0, 2)
-        __builtin_amdgcn_sched_barrier(0);
-        store_a(buf ^ 1);
-        EVC_SPLIT_TERM(1, 0) EVC_SPLIT_TERM(0, 1) EVC_SPLIT_TERM(0, 0)
-#undef EVC_SPLIT_TERM
-        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < SP::NTERM; ++t) {
+            if (t == (SP::NTERM + 1) / 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                store_a(buf ^ 1);           // producer work for the next step sits among the later MFMAs
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = SP::mfma(a[i][SP::qa(t)], b[j][SP::qb(t)], acc[i][j]);
+        }
+        __syncthreads();             // also drains the W DMA (vmcnt) before anyone reads the new buffers
     }
 
     conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
 }
-#else  // EVC_SPLIT_PIPE
+
 // Software-pipelined schedule (default).  Iteration t of the K loop (local step index), buffers cur = t & 1,
 // nxt = cur ^ 1:
 //     top          read the fragments of step t that were not prefetched (a1, b1, a0, b2) from cur -- no barrier
@@ -882,11 +915,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
 
     conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
 }
-#endif  // EVC_SPLIT_PIPE
 
-#if EVC_SPLIT_ROWREUSE
+
 // ---------------------------------------------------------------------------------------------------------------
-// Row-reuse form of the bf16x6 convolution for 3x3 filters on tiles made of whole image rows (128 % W == 0).
+// Row-reuse form of the split-arithmetic convolutions (NP = 3: bf16x6, NP = 2: f16x3) for 3x3 filters on tiles made of whole image rows (128 % W == 0).
 //
 // Under a dense bf16 MFMA load the chip is power-limited (it holds ~1.98 GHz; removing stalls returns only partly as
 // wall time), so what pays is LESS WORK per MFMA.  conv_split_kernel stages every activation element once per
@@ -896,24 +928,28 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
 // are three K-steps whose A fragments are read from that one image at row offsets shifted by tx (the XOR swizzle
 // stays conflict-free under the shift for W >= 32; 2-way at W = 16, 3-way at W = 8).  Weights still arrive per
 // tap by LDS-DMA.  Activation loads, transform + split arithmetic and LDS writes per MFMA: one third.
-// LDS: 2 x 3 planes x (128/W)(W+2) rows x 32 B for the activations + 2 x 3 x BN x 32 B for the weights (61-68 KB).
+// LDS: 2 x NP planes x (128/W)(W+2) rows x 32 B for the activations + 2 x NP x BN x 32 B for the weights (bf16x6: 61-68 KB,
+// f16x3: 41-45 KB).
 // WM = 2: 128-pixel tile, 4 waves, 2 workgroups per CU.  WM = 4: 256-pixel tile, 8 waves, 1 workgroup per CU -- the
 // weight slab is shared by twice the MFMAs (weight DMA per MFMA halved; it costs ~12 % at WM = 2); used for grids
 // that still offer >= 2 rounds of 256-pixel tiles.
-template <int WM, int TN, int MODE>
-__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kernel(ConvK p) {
+template <int NP, int WM, int TN, int MODE>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split_rr_kernel(ConvK p) {
+    typedef Split<NP> SP;
+    typedef typename SP::vec vec;
     constexpr int TM = 2;
     constexpr int BM = 64 * WM;
     constexpr int NT = 128 * WM;
     constexpr int BN = 64 * TN;
     constexpr int RB = 32;
-    constexpr int NWD = WM == 2 ? (6 * TN + 3) / 4 : TN;        // WM = 4: waves 0..5 move TN pieces each (6*TN in all)
+    constexpr int NPIECE = NP * 2 * TN;                         // weight DMA pieces of 1 KiB per K-step
+    constexpr int NWD = WM == 2 ? (NPIECE + 3) / 4 : TN;        // WM = 4: waves 0..2*NP-1 move TN pieces each
     constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     const int SR = (BM / p.W) * (p.W + 2);            // staged rows: every image row of the tile + 2 halo pixels
     const int APL = SR * RB;                          // bytes per activation plane
-    char* const As = smem_b;                          // [2][3][SR][32 B]
-    char* const Ws = smem_b + 2 * 3 * APL;            // [2][3][BN][32 B]
+    char* const As = smem_b;                          // [2][NP][SR][32 B]
+    char* const Ws = smem_b + 2 * NP * APL;           // [2][NP][BN][32 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -977,15 +1013,15 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kerne
 
     unsigned wsrc[NWD];
     int wdst[NWD];
-    const bool w_active = WM == 2 || wave < 6;                         // wave-uniform
+    const bool w_active = WM == 2 || wave < 2 * NP;                    // wave-uniform
 #pragma unroll
     for (int j = 0; j < NWD; ++j) {
-        const int idx = WM == 2 ? min(wave + 4 * j, 6 * TN - 1) : min(wave * TN + j, 6 * TN - 1);
+        const int idx = WM == 2 ? min(wave + 4 * j, NPIECE - 1) : min(wave * TN + j, NPIECE - 1);
         const int part = idx / (2 * TN), seg = idx - part * (2 * TN);
         wsrc[j] = (unsigned)((part * p.CoPad + n0 + seg * 32) * RB + lane * 16);
         wdst[j] = (part * BN + seg * 32) * RB;
     }
-    const unsigned slab = 3u * (unsigned)p.CoPad * RB;
+    const unsigned slab = (unsigned)NP * (unsigned)p.CoPad * RB;
     const unsigned w_tap = (unsigned)p.nchunk * slab;
     const unsigned w_wrap = slab - 9u * w_tap;
 
@@ -1028,7 +1064,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kerne
     };
     auto dma_w = [&](int wb) {
         const char* wt = reinterpret_cast<const char*>(p.w) + w_off;
-        char* wl = Ws + wb * 3 * BN * RB;
+        char* wl = Ws + wb * NP * BN * RB;
         if (w_active) {
 #pragma unroll
             for (int j = 0; j < ((EVC_CONV_ABLATE & 1) ? 0 : NWD); ++j)
@@ -1041,12 +1077,11 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kerne
         if (w_ty == 3) { w_ty = 0; w_off += w_wrap; }
     };
     auto store_a = [&](int ab) {
-        bf16x8 p1, p2, p3;
-        split3_bf16(transform<MODE>(areg[0], ca[0], cs[0], aok), transform<MODE>(areg[1], ca[1], cs[1], aok), p1, p2, p3);
-        char* A = As + ab * 3 * APL + a_lds;
-        *reinterpret_cast<bf16x8*>(A) = p1;
-        *reinterpret_cast<bf16x8*>(A + APL) = p2;
-        *reinterpret_cast<bf16x8*>(A + 2 * APL) = p3;
+        vec pl[NP];
+        SP::split(transform<MODE>(areg[0], ca[0], cs[0], aok), transform<MODE>(areg[1], ca[1], cs[1], aok), pl);
+        char* A = As + ab * NP * APL + a_lds;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<vec*>(A + q * APL) = pl[q];
     };
 
     f32x16 acc[TM][TN];
@@ -1058,7 +1093,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kerne
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // zero both activation images once: the halo pixels stay zero for the whole kernel
-    for (int o = tid * 16; o < 2 * 3 * APL; o += NT * 16) *reinterpret_cast<float4*>(As + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int o = tid * 16; o < 2 * NP * APL; o += NT * 16) *reinterpret_cast<float4*>(As + o) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
     if (nmac > 0) {
@@ -1072,19 +1107,20 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kerne
     __syncthreads();
 
     int wb = 0, sidx = 0;        // weight buffer of the current K-step, K-step index inside this split
-#define EVC_RR_TERM(qa, qb)                                                                             \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)      \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
+#define EVC_RR_TERMS(T0, T1)                                                                            \
+    _Pragma("unroll") for (int t = T0; t < T1; ++t)                                                     \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)  \
+            acc[i][j] = SP::mfma(a[i][SP::qa(t)], b[j][SP::qb(t)], acc[i][j]);
 #define EVC_RR_FRAGS(TX)                                                                                \
-    bf16x8 a[TM][3], b[TN][3];                                                                          \
+    vec a[TM][NP], b[TN][NP];                                                                           \
     {                                                                                                   \
-        const char* Ab = As + ab * 3 * APL;                                                             \
-        const char* Wb = Ws + wb * 3 * BN * RB + w_rd;                                                  \
-        _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                 \
+        const char* Ab = As + ab * NP * APL;                                                            \
+        const char* Wb = Ws + wb * NP * BN * RB + w_rd;                                                 \
+        _Pragma("unroll") for (int q = 0; q < NP; ++q) {                                                \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
-                a[i][q] = *reinterpret_cast<const bf16x8*>(Ab + q * APL + ard[i][TX]);                  \
+                a[i][q] = *reinterpret_cast<const vec*>(Ab + q * APL + ard[i][TX]);                     \
             _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
-                b[j][q] = *reinterpret_cast<const bf16x8*>(Wb + (q * BN + j * 32) * RB);                \
+                b[j][q] = *reinterpret_cast<const vec*>(Wb + (q * BN + j * 32) * RB);                   \
         }                                                                                               \
     }
 #define EVC_RR_NEXT_W()                                                                                 \
@@ -1100,7 +1136,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kerne
             load_a();
             __builtin_amdgcn_sched_barrier(0);
             EVC_RR_FRAGS(0)
-            EVC_RR_TERM(2, 0) EVC_RR_TERM(1, 1) EVC_RR_TERM(0, 2) EVC_RR_TERM(1, 0) EVC_RR_TERM(0, 1) EVC_RR_TERM(0, 0)
+            EVC_RR_TERMS(0, SP::NTERM)
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // weight DMA landed, loads stay in flight
             __builtin_amdgcn_sched_barrier(0);
@@ -1109,625 +1145,28 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kerne
         {   // ---- tx = 1 ----
             EVC_RR_NEXT_W()
             EVC_RR_FRAGS(1)
-            EVC_RR_TERM(2, 0) EVC_RR_TERM(1, 1) EVC_RR_TERM(0, 2) EVC_RR_TERM(1, 0) EVC_RR_TERM(0, 1) EVC_RR_TERM(0, 0)
+            EVC_RR_TERMS(0, SP::NTERM)
             __syncthreads();
             wb ^= 1; ++sidx;
         }
         {   // ---- tx = 2: stage the next macro-step's activation image among the MFMAs ----
             EVC_RR_NEXT_W()
             EVC_RR_FRAGS(2)
-            EVC_RR_TERM(2, 0) EVC_RR_TERM(1, 1) EVC_RR_TERM(0, 2)
+            EVC_RR_TERMS(0, SP::NTERM / 2)
             __builtin_amdgcn_sched_barrier(0);
             store_a(ab ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            EVC_RR_TERM(1, 0) EVC_RR_TERM(0, 1) EVC_RR_TERM(0, 0)
+            EVC_RR_TERMS(SP::NTERM / 2, SP::NTERM)
             __syncthreads();
             wb ^= 1; ++sidx;
         }
     }
-#undef EVC_RR_TERM
+#undef EVC_RR_TERMS
 #undef EVC_RR_FRAGS
 #undef EVC_RR_NEXT_W
 
     conv_epilogue<TM, TN, WM>(p, acc, m0, n0, split, wm, wn, l31, half);
 }
-#endif  // EVC_SPLIT_ROWREUSE
-
-#if EVC_SPLIT_PC
-// ---------------------------------------------------------------------------------------------------------------
-// Producer / consumer form of the bf16x6 convolution (128 x 64*TN tile, one 8-wave workgroup per CU).
-//
-// Why: in conv_split_kernel both waves of a SIMD run the same program, fall into step with each other and the
-// MFMA pipe idles whenever both are staging (measured: pipe 49 % busy at 2 workgroups per CU although no single
-// resource is saturated -- L2 -> CU traffic 6.1 TB/s of ~17, TA 28 %, LDS ~30 %).  Here the roles are split:
-//   waves 0-3  CONSUMERS  ds_read_b128 fragments + 36 MFMAs per K-step, nothing else, raised priority; the fragments
-//                         of step t+1 are read while the MFMAs of step t run (two register sets, loop unrolled by 2)
-//   waves 4-7  PRODUCERS  activation gather -> GroupNorm/SiLU -> exact 3-way bf16 split -> LDS, weight slabs by
-//                         LDS-DMA, through a ring of NS = 5 LDS stages (150 KB).  Every load and every DMA is issued
-//                         TWO K-steps before it is needed (one step is ~0.6 us, an L2 / MALL round trip under load
-//                         is longer): two alternating register sets for the activations, and a COUNTED vmcnt wait
-//                         that leaves the two youngest iterations' operations in flight.
-// Waves w and w + 4 share a SIMD, so every SIMD hosts one of each and the producer's VALU / memory instructions issue
-// in the shadow of the consumer's MFMAs.  One barrier per K-step: barrier(t+1) publishes stage t+2 and tells the
-// producers that the consumers have the fragments of step t+1 in registers.
-template <int TN, int MODE>
-__global__ __launch_bounds__(512, 1) void conv_split_pc_kernel(ConvK p) {
-    constexpr int TM = 2;
-    constexpr int BM = 128;
-    constexpr int BN = 64 * TN;
-    constexpr int RB = 32;
-    constexpr int NS = 5;
-    constexpr int STAGE = 3 * (BM + BN) * RB;            // bytes per ring stage: A planes, then W planes
-    constexpr int WOFF = 3 * BM * RB;                    // W planes inside a stage
-    constexpr int NWD = (6 * TN + 3) / 4;                // weight DMA instructions per producer wave and K-step
-    constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
-    constexpr int VOPS = NWD + 2 + (HAS_COEF ? 4 : 0);   // vector-memory operations a producer wave issues per K-step
-    constexpr int VWAIT = EVC_CONV_ABLATE ? 0 : 2 * VOPS;
-    extern __shared__ __attribute__((aligned(16))) char smem_b[];
-
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    const int split = blockIdx.z;
-    const int s_begin = split * p.steps_per_split;
-    const int nst = min(p.nsteps, s_begin + p.steps_per_split) - s_begin;
-
-    if (wave < 4) {
-        // ================================ consumer ================================
-        __builtin_amdgcn_s_setprio(EVC_PC_CONSUMER_PRIO);
-        const int wm = wave >> 1, wn = wave & 1;
-        const int l31 = lane & 31, half = lane >> 5;
-        const int fr = l31 * RB + 16 * (half ^ ((l31 >> 3) & 1));
-        const char* const a_base = smem_b + wm * 32 * TM * RB + fr;
-        const char* const w_base = smem_b + WOFF + wn * 32 * TN * RB + fr;
-        f32x16 acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        bf16x8 a0[TM][3], b0[TN][3], a1[TM][3], b1[TN][3];
-
-#define EVC_PC_READ(A, B, SOFF)                                                                              \
-        _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                      \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
-                A[i][q] = *reinterpret_cast<const bf16x8*>(a_base + (SOFF) + (q * BM + i * 32) * RB);        \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
-                B[j][q] = *reinterpret_cast<const bf16x8*>(w_base + (SOFF) + (q * BN + j * 32) * RB);        \
-        }
-#define EVC_PC_TERM(A, B, qa, qb)                                                                            \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)       \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][qa], B[j][qb], acc[i][j], 0, 0, 0);
-#define EVC_PC_MFMAS(A, B)                                                                                   \
-        EVC_PC_TERM(A, B, 2, 0) EVC_PC_TERM(A, B, 1, 1) EVC_PC_TERM(A, B, 0, 2)                              \
-        EVC_PC_TERM(A, B, 1, 0) EVC_PC_TERM(A, B, 0, 1) EVC_PC_TERM(A, B, 0, 0)
-#define EVC_PC_BARRIER() asm volatile("s_barrier" ::: "memory")
-#define EVC_PC_NEXT(x) x = (x + STAGE == NS * STAGE) ? 0 : x + STAGE
-
-        int soff = 0;                                       // byte offset of the stage being READ
-        EVC_PC_BARRIER();                                   // barrier(0): stages 0 and 1 are published
-        if (nst > 0) { EVC_PC_READ(a0, b0, 0) }
-        int t = 0;
-        for (; t + 1 < nst; t += 2) {
-            EVC_PC_NEXT(soff);
-            EVC_PC_READ(a1, b1, soff)                       // fragments of step t+1 while the MFMAs of step t run
-            __builtin_amdgcn_sched_barrier(0);              // (keep the reads up here: the scheduler would sink them)
-            EVC_PC_MFMAS(a0, b0)
-            EVC_PC_BARRIER();                               // barrier(t+1)
-            EVC_PC_NEXT(soff);
-            EVC_PC_READ(a0, b0, soff)
-            __builtin_amdgcn_sched_barrier(0);
-            EVC_PC_MFMAS(a1, b1)
-            EVC_PC_BARRIER();                               // barrier(t+2)
-        }
-        if (t < nst) {
-            EVC_PC_MFMAS(a0, b0)
-            EVC_PC_BARRIER();
-        }
-#undef EVC_PC_READ
-#undef EVC_PC_TERM
-#undef EVC_PC_MFMAS
-        __builtin_amdgcn_s_setprio(0);
-        conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
-    } else {
-        // ================================ producer ================================
-        const int pw = wave - 4;
-        const int tid = threadIdx.x - 256;
-        const int row = tid >> 1, kh = tid & 1;
-        const int padH = p.KH >> 1, padW = p.KW >> 1;
-        const int Ct = p.C0 + p.C1;
-        unsigned off0, off1, okmask = 0;
-        int rb;
-        {
-            const int m = m0 + row;
-            const bool valid = m < p.M;
-            const int mm = valid ? m : 0;
-            const int b = mm / p.HW;
-            const int rem = mm - b * p.HW;
-            const int y = rem / p.W;
-            const int x = rem - y * p.W;
-            rb = b;
-            off0 = ((unsigned)mm * (unsigned)p.ld0 + 8u * kh) * 4u;
-            off1 = ((unsigned)mm * (unsigned)p.ld1 + 8u * kh) * 4u;
-            for (int ty = 0; ty < p.KH; ++ty)
-                for (int tx = 0; tx < p.KW; ++tx) {
-                    const int yy = y + ty - padH, xx = x + tx - padW;
-                    const bool ok = valid && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-                    okmask |= (ok ? 1u : 0u) << (ty * p.KW + tx);
-                }
-        }
-        const int a_lds = row * RB + 16 * (kh ^ ((row >> 3) & 1));
-        unsigned wsrc[NWD];
-        int wdst[NWD];
-#pragma unroll
-        for (int j = 0; j < NWD; ++j) {
-            const int idx = min(pw + 4 * j, 6 * TN - 1);
-            const int part = idx / (2 * TN), seg = idx - part * (2 * TN);
-            wsrc[j] = (unsigned)((part * p.CoPad + n0 + seg * 32) * RB + lane * 16);
-            wdst[j] = WOFF + (part * BN + seg * 32) * RB;
-        }
-        const unsigned slab = 3u * (unsigned)p.CoPad * RB;
-        const unsigned w_tap = (unsigned)p.nchunk * slab;
-        const unsigned w_wrap = slab - (unsigned)(p.KH * p.KW) * w_tap;
-        int w_ty, w_tx, l_chunk, l_ty, l_tx;
-        {
-            const int taps = p.KH * p.KW;
-            l_chunk = s_begin / taps;
-            const int tap = s_begin - l_chunk * taps;
-            l_ty = w_ty = tap / p.KW;
-            l_tx = w_tx = tap - l_ty * p.KW;
-        }
-        unsigned w_off = (unsigned)((w_ty * p.KW + w_tx) * p.nchunk + l_chunk) * slab;
-        const char* a_src; int a_px, a_delta; unsigned a_safe; bool a_first;
-        auto chunk_setup = [&]() {
-            const int c = l_chunk * KC;
-            a_first = c < p.C0;
-            a_src = reinterpret_cast<const char*>(a_first ? p.src0 : p.src1);
-            a_px = (a_first ? p.ld0 : p.ld1) * 4;
-            const int cc = a_first ? c : c - p.C0;
-            a_delta = ((l_ty - padH) * p.W + (l_tx - padW)) * a_px + cc * 4;
-            a_safe = (unsigned)(cc + 8 * kh) * 4u;
-        };
-        // one staged K-step: raw activations, the GroupNorm coefficients of its chunk, in-image flag
-        struct Staged { float4 v[2], ca[2], cs[2]; bool ok; };
-        Staged s0, s1;
-        auto load_a = [&](Staged& d) {                     // the step L points at; always VOPS - NWD operations
-            if (EVC_CONV_ABLATE & 2) return;
-            d.ok = (okmask >> (l_ty * p.KW + l_tx)) & 1u;
-            const unsigned o = d.ok ? (a_first ? off0 : off1) + (unsigned)a_delta : a_safe;
-            d.v[0] = *reinterpret_cast<const float4*>(a_src + o);
-            d.v[1] = *reinterpret_cast<const float4*>(a_src + o + 16);
-            if (HAS_COEF) {
-                const size_t co = (size_t)rb * Ct + l_chunk * KC + 8 * kh;
-                d.ca[0] = *reinterpret_cast<const float4*>(p.coef_a + co);
-                d.ca[1] = *reinterpret_cast<const float4*>(p.coef_a + co + 4);
-                d.cs[0] = *reinterpret_cast<const float4*>(p.coef_s + co);
-                d.cs[1] = *reinterpret_cast<const float4*>(p.coef_s + co + 4);
-            }
-        };
-        auto dma_w = [&](int soff) {
-            const char* wt = reinterpret_cast<const char*>(p.w) + w_off;
-            char* wl = smem_b + soff;
-#pragma unroll
-            for (int j = 0; j < ((EVC_CONV_ABLATE & 1) ? 0 : NWD); ++j)
-                __builtin_amdgcn_global_load_lds((glb_void*)(wt + wsrc[j]), (lds_void*)(wl + wdst[j]), 16, 0, 0);
-        };
-        auto advance_w = [&]() {
-            ++w_tx; w_off += w_tap;
-            if (w_tx == p.KW) { w_tx = 0; ++w_ty; }
-            if (w_ty == p.KH) { w_ty = 0; w_off += w_wrap; }
-        };
-        auto advance_l = [&]() {
-            ++l_tx; a_delta += a_px;
-            if (l_tx == p.KW) { l_tx = 0; ++l_ty; a_delta += (p.W - p.KW) * a_px; }
-            if (l_ty == p.KH) { l_ty = 0; ++l_chunk; chunk_setup(); }
-        };
-        auto store_a = [&](const Staged& d, int soff) {
-            if (EVC_CONV_ABLATE & 2) return;
-            bf16x8 p1, p2, p3;
-            split3_bf16(transform<MODE>(d.v[0], d.ca[0], d.cs[0], d.ok), transform<MODE>(d.v[1], d.ca[1], d.cs[1], d.ok), p1, p2, p3);
-            char* A = smem_b + soff + a_lds;
-            *reinterpret_cast<bf16x8*>(A) = p1;
-            *reinterpret_cast<bf16x8*>(A + BM * RB) = p2;
-            *reinterpret_cast<bf16x8*>(A + 2 * BM * RB) = p3;
-        };
-
-        // ---- prologue: stages 0 and 1 complete; DMA of stages 2, 3 and the activations of steps 2, 3 in flight ----
-        chunk_setup();
-        load_a(s0); dma_w(0 * STAGE); store_a(s0, 0 * STAGE);
-        if (1 < nst) { advance_l(); advance_w(); }
-        load_a(s0); dma_w(1 * STAGE); store_a(s0, 1 * STAGE);
-        if (2 < nst) { advance_l(); advance_w(); }
-        load_a(s0); dma_w(2 * STAGE);
-        if (3 < nst) { advance_l(); advance_w(); }
-        load_a(s1); dma_w(3 * STAGE);
-        if (4 < nst) advance_w();
-        int st_store = 2 * STAGE, st_dma = 4 * STAGE;
-        // everything but the two youngest steps' operations has landed
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VWAIT) : "memory");          // barrier(0)
-#define EVC_PC_PROD(SET, T)                                                                                  \
-        dma_w(st_dma);                                      /* weights of step T+4 */                        \
-        if ((T) + 5 < nst) advance_w();                                                                      \
-        store_a(SET, st_store);                             /* activations of step T+2 (loaded 2 steps ago) */ \
-        if ((T) + 4 < nst) advance_l();                                                                      \
-        load_a(SET);                                        /* activations of step T+4 */                    \
-        EVC_PC_NEXT(st_store); EVC_PC_NEXT(st_dma);                                                          \
-        /* DMA of step T+2 (issued two iterations ago) has landed; the two youngest iterations stay in flight */ \
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VWAIT) : "memory");   /* barrier(T+1) */
-        int t = 0;
-        for (; t + 1 < nst; t += 2) {
-            EVC_PC_PROD(s0, t)
-            EVC_PC_PROD(s1, t + 1)
-        }
-        if (t < nst) { EVC_PC_PROD(s0, t) }
-#undef EVC_PC_PROD
-    }
-#undef EVC_PC_NEXT
-#undef EVC_PC_BARRIER
-}
-#endif  // EVC_SPLIT_PC
-
-#if EVC_CONV_PC
-// Producer / consumer specialisation of the same tiling (128 x 64*TN tile, TM = 2).  A workgroup has 8 waves:
-// waves 0-3 are CONSUMERS (fragment reads + MFMAs only, raised priority), waves 4-7 are PRODUCERS (activation
-// gather + transform + LDS write, weight slab DMA).  Waves w and w + 4 share a SIMD, so every SIMD hosts one of
-// each: the consumer's in-order stream is the bare MFMA skeleton, the producer's VALU / memory instructions fill
-// the issue slots between MFMAs.  One barrier per K-step, double-buffered LDS as in conv_igemm_kernel.
-template <int TN, int MODE>
-__global__ __launch_bounds__(512, EVC_CONV_PC_OCC) void conv_pc_kernel(ConvK p) {
-    constexpr int TM = 2;
-    constexpr int BM = 128;
-    constexpr int BN = 64 * TN;
-    constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const As = smem;                    // [2][BM][16]
-    float* const Ws = smem + 2 * BM * KC;      // [2][BN][16]
-
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    const int split = blockIdx.z;
-    const int s_begin = split * p.steps_per_split;
-    const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
-    const bool consumer = __builtin_amdgcn_readfirstlane(threadIdx.x) < 256;    // wave-uniform role
-
-    if (consumer) {
-        __builtin_amdgcn_s_setprio(3);
-        const int tid = threadIdx.x;
-        const int lane = tid & 63, wave = tid >> 6;
-        const int wm = wave >> 1, wn = wave & 1;
-        const int l31 = lane & 31, half = lane >> 5;
-        const int fsw = (l31 >> 2) & 3;
-        const int rd0 = 4 * ((0 + half) ^ fsw), rd1 = 4 * ((2 + half) ^ fsw);
-        const int a_rd = (wm * 64 + l31) * KC, w_rd = (wn * 32 * TN + l31) * KC;
-        f32x16 acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        __syncthreads();                                   // prologue tiles are in LDS
-        for (int s = s_begin; s < s_end; ++s) {
-            const int buf = (s - s_begin) & 1;
-            const float* Ab = As + buf * BM * KC + a_rd;
-            const float* Wb = Ws + buf * BN * KC + w_rd;
-            float4 a0[TM], b0[TN], a1[TM], b1[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a0[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * KC + rd0);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b0[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * KC + rd0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a1[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * KC + rd1);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b1[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * KC + rd1);
-            mfma_group<TM, TN>(acc, a0, b0);
-            mfma_group<TM, TN>(acc, a1, b1);
-            __syncthreads();
-        }
-        __builtin_amdgcn_s_setprio(0);
-        conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
-    } else {
-        const int tid = threadIdx.x - 256;                 // producer thread id 0..255
-        const int wave = tid >> 6;
-        const int k4 = tid & 3;
-        const int padH = p.KH >> 1, padW = p.KW >> 1;
-        const int Ct = p.C0 + p.C1;
-        unsigned off0[TM], off1[TM], okmask[TM];
-        int rb[TM], a_lds[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = (tid >> 2) + 64 * i;
-            const int m = m0 + row;
-            const bool valid = m < p.M;
-            const int mm = valid ? m : 0;
-            const int b = mm / p.HW;
-            const int rem = mm - b * p.HW;
-            const int y = rem / p.W;
-            const int x = rem - y * p.W;
-            rb[i] = b;
-            off0[i] = ((unsigned)mm * (unsigned)p.ld0 + 4u * k4) * 4u;
-            off1[i] = ((unsigned)mm * (unsigned)p.ld1 + 4u * k4) * 4u;
-            unsigned mask = 0;
-            for (int ty = 0; ty < p.KH; ++ty)
-                for (int tx = 0; tx < p.KW; ++tx) {
-                    const int yy = y + ty - padH, xx = x + tx - padW;
-                    mask |= ((valid && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? 1u : 0u) << (ty * p.KW + tx);
-                }
-            okmask[i] = mask;
-            a_lds[i] = row * KC + 4 * (k4 ^ ((row >> 2) & 3));
-        }
-        int c_chunk, c_ty, c_tx;
-        {
-            const int taps = p.KH * p.KW;
-            c_chunk = s_begin / taps;
-            const int tap = s_begin - c_chunk * taps;
-            c_ty = tap / p.KW;
-            c_tx = tap - c_ty * p.KW;
-        }
-        float4 areg[TM], ca[TM], cs[TM];
-        bool aok[TM];
-        auto load_coefs = [&]() {
-            if (HAS_COEF) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const size_t co = (size_t)rb[i] * Ct + c_chunk * KC + 4 * k4;
-                    ca[i] = *reinterpret_cast<const float4*>(p.coef_a + co);
-                    cs[i] = *reinterpret_cast<const float4*>(p.coef_s + co);
-                }
-            }
-        };
-        auto load_a = [&]() {                              // activation gather of the cursor's step -> registers
-            const int c = c_chunk * KC;
-            const bool first = c < p.C0;
-            const char* src = reinterpret_cast<const char*>(first ? p.src0 : p.src1);
-            const int ld = first ? p.ld0 : p.ld1;
-            const int tap = c_ty * p.KW + c_tx;
-            const int delta = (((c_ty - padH) * p.W + (c_tx - padW)) * ld + (first ? c : c - p.C0)) * 4;
-            const unsigned safe = (unsigned)((first ? c : c - p.C0) + 4 * k4) * 4u;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                aok[i] = (okmask[i] >> tap) & 1u;
-                const unsigned o = aok[i] ? (first ? off0[i] : off1[i]) + (unsigned)delta : safe;
-                areg[i] = *reinterpret_cast<const float4*>(src + o);
-            }
-        };
-        auto dma_w = [&](int buf) {                        // weight slab of the cursor's step -> LDS buffer `buf`
-            const int tap = c_ty * p.KW + c_tx;
-            const float* wt = p.w + ((size_t)(tap * p.nchunk + c_chunk) * p.CoPad + n0) * KC;
-            float* wl = Ws + buf * BN * KC;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                __builtin_amdgcn_global_load_lds((glb_void*)(wt + (size_t)(tid + 256 * j) * 4),
-                                                 (lds_void*)(wl + (wave * 16 + 64 * j) * KC), 16, 0, 0);
-        };
-        auto advance = [&]() {
-            ++c_tx;
-            if (c_tx == p.KW) { c_tx = 0; ++c_ty; }
-            if (c_ty == p.KH) { c_ty = 0; ++c_chunk; }
-        };
-        auto store_a = [&](int buf) {
-            float* A = As + buf * BM * KC;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                *reinterpret_cast<float4*>(A + a_lds[i]) = transform<MODE>(areg[i], ca[i], cs[i], aok[i]);
-        };
-        // Prologue: step s_begin fully staged; the gather of step s_begin + 1 is left in flight in registers.
-        if (s_begin < s_end) {
-            load_coefs();
-            load_a();
-            store_a(0);
-            dma_w(0);
-            if (s_begin + 1 < s_end) {
-                const int prev_chunk = c_chunk;
-                advance();
-                if (HAS_COEF && c_chunk != prev_chunk) load_coefs();
-                load_a();
-            }
-        }
-        __syncthreads();     // drains everything once (prologue only)
-        if (s_begin + 1 < s_end) load_a();   // re-issue: the barrier above waited for the first copy
-        for (int s = s_begin; s < s_end; ++s) {
-            const int buf = (s - s_begin) & 1;
-            bool reloaded = false;
-            if (s + 1 < s_end) {
-                store_a(buf ^ 1);              // registers hold step s+1 (issued a whole step ago)
-                dma_w(buf ^ 1);                // weights of step s+1 (cursor points at s+1)
-                if (s + 2 < s_end) {
-                    const int prev_chunk = c_chunk;
-                    advance();
-                    if (HAS_COEF && c_chunk != prev_chunk) { load_coefs(); reloaded = true; }
-                    load_a();                  // step s+2 stays in flight across the barrier
-                }
-            }
-            // Wait for the LDS writes and the weight DMA (older), NOT for the gathers issued after it.
-            if (s + 2 < s_end) {
-                if (reloaded) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * TM) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(TM) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-        }
-    }
-}
-#endif  // EVC_CONV_PC
-
-#if EVC_CONV_ROWREUSE
-// Row-reuse variant: same GEMM tiling, but the activation operand of one channel chunk is staged ONCE per kernel
-// row instead of once per tap.  Precondition (checked by the host): the 64*TM-pixel tile consists of whole image
-// rows (W divides 64*TM) and a split covers whole chunks (steps_per_split % (KH*KW) == 0).
-// Per chunk the LDS holds KH sub-tiles; sub-tile u, element j = act(affine(src[pixel m0+j shifted by (u-padH) rows]))
-// or 0 when that source row is outside the image.  Tap (u, v) reads sub-tile u at LDS rows j + (v - padW): the
-// horizontally shifted neighbour.  Lanes whose own pixel has no such neighbour inside the image row (x + v - padW
-// outside [0, W)) select 0 -- those are exactly the reads that would otherwise wrap into the adjacent image row or
-// the (unwritten) pad rows.  Producer work per chunk: KH row gathers + transforms + LDS writes instead of KH*KW.
-template <int TM, int TN, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_rowreuse_kernel(ConvK p) {
-    constexpr int BM = 64 * TM;
-    constexpr int BN = 64 * TN;
-    constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int padH = p.KH >> 1, padW = p.KW >> 1;
-    const int sub_rows = BM + 2 * padW;
-    const int a_floats = p.KH * sub_rows * KC;      // one activation buffer (all sub-tiles of a chunk)
-    float* const As = smem;                         // [2][KH][sub_rows][16]
-    float* const Ws = smem + 2 * a_floats;          // [2][BN][16]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    const int split = blockIdx.z;
-    const int taps = p.KH * p.KW;
-    const int s_begin = split * p.steps_per_split;
-    const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
-    const int c_begin = s_begin / taps, c_end = s_end / taps;   // whole chunks by precondition
-
-    // ---- producer state: rows tid/4 (+64), 4-channel column k4 ----
-    const int k4 = tid & 3;
-    const int Ct = p.C0 + p.C1;
-    unsigned off0[TM], off1[TM], dyok[TM];
-    int rb[TM], prow[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = (tid >> 2) + 64 * i;
-        const int m = m0 + row;
-        const bool valid = m < p.M;
-        const int mm = valid ? m : 0;
-        const int b = mm / p.HW;
-        const int y = (mm - b * p.HW) / p.W;
-        rb[i] = b; prow[i] = row;
-        off0[i] = ((unsigned)mm * (unsigned)p.ld0 + 4u * k4) * 4u;
-        off1[i] = ((unsigned)mm * (unsigned)p.ld1 + 4u * k4) * 4u;
-        unsigned mask = 0;
-        for (int u = 0; u < p.KH; ++u) mask |= ((valid && y + u - padH >= 0 && y + u - padH < p.H) ? 1u : 0u) << u;
-        dyok[i] = mask;
-    }
-    // ---- consumer state: tile row of this lane's pixels and their x coordinate (tile starts at x = 0) ----
-    int rrow[TM], px[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        rrow[i] = wm * 32 * TM + 32 * i + l31;
-        px[i] = rrow[i] % p.W;
-    }
-    const int w_rd = (wn * 32 * TN + l31) * KC;
-    const int wsw = (l31 >> 2) & 3;                    // weight rows: tile / wave offsets are multiples of 16
-    const int wrd0 = 4 * ((0 + half) ^ wsw), wrd1 = 4 * ((2 + half) ^ wsw);
-
-    float4 areg[TM], ca[TM], cs[TM];
-    bool aok[TM];
-
-    auto load_coefs = [&](int chunk) {
-        if (HAS_COEF) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const size_t co = (size_t)rb[i] * Ct + chunk * KC + 4 * k4;
-                ca[i] = *reinterpret_cast<const float4*>(p.coef_a + co);
-                cs[i] = *reinterpret_cast<const float4*>(p.coef_s + co);
-            }
-        }
-    };
-    auto load_sub = [&](int chunk, int u) {            // gather kernel row u of `chunk` into registers
-        const int c = chunk * KC;
-        const bool first = c < p.C0;
-        const char* src = reinterpret_cast<const char*>(first ? p.src0 : p.src1);
-        const int ld = first ? p.ld0 : p.ld1;
-        const int cc = first ? c : c - p.C0;
-        const int delta = ((u - padH) * p.W * ld + cc) * 4;
-        const unsigned safe = (unsigned)(cc + 4 * k4) * 4u;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            aok[i] = (dyok[i] >> u) & 1u;
-            const unsigned o = aok[i] ? (first ? off0[i] : off1[i]) + (unsigned)delta : safe;
-            areg[i] = *reinterpret_cast<const float4*>(src + o);
-        }
-    };
-    auto store_sub = [&](int abuf, int u) {
-        float* A = As + abuf * a_floats;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int lrow = u * sub_rows + padW + prow[i];
-            *reinterpret_cast<float4*>(A + lrow * KC + 4 * (k4 ^ ((lrow >> 2) & 3))) =
-                transform<MODE>(areg[i], ca[i], cs[i], aok[i]);
-        }
-    };
-    auto dma_w = [&](int chunk, int tap, int wbuf) {
-        const float* wt = p.w + ((size_t)(tap * p.nchunk + chunk) * p.CoPad + n0) * KC;
-        float* wl = Ws + wbuf * BN * KC;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-            __builtin_amdgcn_global_load_lds((glb_void*)(wt + (size_t)(tid + 256 * j) * 4),
-                                             (lds_void*)(wl + (wave * 16 + 64 * j) * KC), 16, 0, 0);
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    if (c_begin < c_end) {
-        load_coefs(c_begin);
-        for (int u = 0; u < p.KH; ++u) { load_sub(c_begin, u); store_sub(0, u); }
-        dma_w(c_begin, 0, 0);
-    }
-    __syncthreads();
-
-    int wbuf = 0;
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
-        const int abuf = (chunk - c_begin) & 1;
-        const bool more_chunks = chunk + 1 < c_end;
-        int ty = 0, tx = 0;
-        for (int t = 0; t < taps; ++t) {
-            // producer, next chunk: kernel row t is gathered at tap t (t < KH), coefficients once per chunk
-            const bool produce = more_chunks && t < p.KH;          // wave-uniform
-            if (produce) {
-                if (t == 0) load_coefs(chunk + 1);
-                load_sub(chunk + 1, t);
-            }
-            // weight slab of the next step (next tap of this chunk, or tap 0 of the next chunk)
-            const bool last_tap = t + 1 == taps;
-            if (!last_tap) dma_w(chunk, t + 1, wbuf ^ 1);
-            else if (more_chunks) dma_w(chunk + 1, 0, wbuf ^ 1);
-
-            const float* A = As + abuf * a_floats;
-            const float* Wb = Ws + wbuf * BN * KC + w_rd;
-            float4 a0[TM], b0[TN], a1[TM], b1[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int lrow = ty * sub_rows + rrow[i] + tx;      // = + padW + (tx - padW)
-                const int f = (lrow >> 2) & 3;
-                const bool ok = (unsigned)(px[i] + tx - padW) < (unsigned)p.W;
-                float4 v0 = *reinterpret_cast<const float4*>(A + lrow * KC + 4 * ((0 + half) ^ f));
-                float4 v1 = *reinterpret_cast<const float4*>(A + lrow * KC + 4 * ((2 + half) ^ f));
-                a0[i].x = ok ? v0.x : 0.f; a0[i].y = ok ? v0.y : 0.f; a0[i].z = ok ? v0.z : 0.f; a0[i].w = ok ? v0.w : 0.f;
-                a1[i].x = ok ? v1.x : 0.f; a1[i].y = ok ? v1.y : 0.f; a1[i].z = ok ? v1.z : 0.f; a1[i].w = ok ? v1.w : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                b0[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * KC + wrd0);
-                b1[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * KC + wrd1);
-            }
-            mfma_group<TM, TN>(acc, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (produce) store_sub(abuf ^ 1, t);
-            mfma_group<TM, TN>(acc, a1, b1);
-            __syncthreads();
-            wbuf ^= 1;
-            if (++tx == p.KW) { tx = 0; ++ty; }
-        }
-    }
-    conv_epilogue<TM, TN>(p, acc, m0, n0, split, wm, wn, l31, half);
-}
-
-#endif  // EVC_CONV_ROWREUSE
 
 // out = act((sum_z ws[z] + bias + res) * scale): deterministic split-K combine.
 // Block = one 64-pixel run x 64 channels, 1024 threads (thread: channel tid & 63, rows tid >> 6, +16, ...):
@@ -1832,6 +1271,49 @@ __global__ void conv_pack_split_kernel(const float* w, __bf16* packed, int Co, i
     }
 }
 
+// f16x3 weights.  Header (F16_HDR_BYTES, written by these kernels): [0] = 1 / (S_a * S_w) as float, [1] = S_w as float,
+// [2] = bit pattern of max|w| (scratch of the reduction).  Body: [KH*KW][Ci/16][2 planes][CoPad][16 fp16], halves swizzled
+// like the LDS image.
+constexpr int F16_HDR_BYTES = 256;
+
+__global__ void conv_absmax_kernel(const float* w, size_t n, unsigned* out_bits) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(w[i]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out_bits, __float_as_uint(m));   // non-negative floats order like their bits
+}
+
+__device__ __forceinline__ float f16_weight_scale(unsigned max_bits) {
+    const float mx = __uint_as_float(max_bits);
+    if (!(mx > 0.f) || !isfinite(mx)) return 1.0f;
+    return ldexpf(1.0f, 14 - ilogbf(mx));            // max|w| * S_w in [2^14, 2^15)
+}
+
+__global__ void conv_pack_f16_kernel(const float* w, char* packed, int Co, int CoPad, int Ci, int KH, int KW) {
+    const int taps = KH * KW, nchunk = Ci / KC;
+    const size_t total = (size_t)taps * nchunk * CoPad * KC;
+    float* hdr = reinterpret_cast<float*>(packed);
+    const float sw = f16_weight_scale(reinterpret_cast<const unsigned*>(packed)[2]);
+    _Float16* body = reinterpret_cast<_Float16*>(packed + F16_HDR_BYTES);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[0] = 1.0f / (F16_ACT_SCALE * sw); hdr[1] = sw; }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % KC);
+        size_t t = i / KC;
+        const int co = (int)(t % CoPad); t /= CoPad;
+        const int chunk = (int)(t % nchunk);
+        const int tap = (int)(t / nchunk);
+        float v = 0.f;
+        if (co < Co) v = w[((size_t)co * Ci + chunk * KC + k) * taps + tap] * sw;
+        const _Float16 a = (_Float16)v;
+        const _Float16 b = (_Float16)(v - (float)a);
+        const int pos = (((k >> 3) ^ ((co >> 3) & 1)) << 3) | (k & 7);
+        const size_t base = (size_t)(tap * nchunk + chunk) * 2 * CoPad * KC;
+        body[base + ((size_t)0 * CoPad + co) * KC + pos] = a;
+        body[base + ((size_t)1 * CoPad + co) * KC + pos] = b;
+    }
+}
+
 int pick_tn(int CoPad) {
     if (CoPad % 192 == 0) return 3;
     if (CoPad % 128 == 0) return 2;
@@ -1856,20 +1338,33 @@ extern "C" int evc_conv_pack_weights_f32(const float* w, float* packed, int Co, 
 }
 
 extern "C" long long evc_conv_packed_bytes(int Co, int Ci, int KH, int KW, int arith) {
-    if (arith != EVC_ARITH_F32 && arith != EVC_ARITH_BF16X6) return EVC_EINVAL;
     const long long elems = evc_conv_packed_floats(Co, Ci, KH, KW);
-    return arith == EVC_ARITH_BF16X6 ? elems * 6 : elems * 4;     // three bf16 planes vs one f32
+    switch (arith) {
+        case EVC_ARITH_F32: return elems * 4;
+        case EVC_ARITH_BF16X6: return elems * 6;                      // three bf16 planes
+        case EVC_ARITH_F16X3: return F16_HDR_BYTES + elems * 4;       // header + two fp16 planes
+        default: return EVC_EINVAL;
+    }
 }
 
 extern "C" int evc_conv_pack_weights(const float* w, void* packed, int Co, int Ci, int KH, int KW, int arith,
                                      void* stream) {
     if (arith == EVC_ARITH_F32) return evc_conv_pack_weights_f32(w, (float*)packed, Co, Ci, KH, KW, stream);
-    if (arith != EVC_ARITH_BF16X6) return EVC_EINVAL;
+    if (arith != EVC_ARITH_BF16X6 && arith != EVC_ARITH_F16X3) return EVC_EINVAL;
     if (!w || !packed || Co <= 0 || Ci <= 0 || Ci % KC != 0 || KH <= 0 || KW <= 0) return EVC_EINVAL;
     const long long total = evc_conv_packed_floats(Co, Ci, KH, KW);
     int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(conv_pack_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)packed, Co,
-                       evc_conv_co_pad(Co), Ci, KH, KW);
+    hipStream_t st = (hipStream_t)stream;
+    if (arith == EVC_ARITH_BF16X6) {
+        hipLaunchKernelGGL(conv_pack_split_kernel, dim3(grid), dim3(256), 0, st, w, (__bf16*)packed, Co,
+                           evc_conv_co_pad(Co), Ci, KH, KW);
+    } else {
+        if (hipMemsetAsync(packed, 0, F16_HDR_BYTES, st) != hipSuccess) return EVC_ELAUNCH;
+        const size_t n = (size_t)Co * Ci * KH * KW;
+        hipLaunchKernelGGL(conv_absmax_kernel, dim3(grid), dim3(256), 0, st, w, n, reinterpret_cast<unsigned*>(packed) + 2);
+        hipLaunchKernelGGL(conv_pack_f16_kernel, dim3(grid), dim3(256), 0, st, w, (char*)packed, Co,
+                           evc_conv_co_pad(Co), Ci, KH, KW);
+    }
     return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
 }
 
@@ -1884,7 +1379,7 @@ static int conv_validate(const evc_conv_args* a) {
     if (a->KH <= 0 || a->KW <= 0 || !(a->KH & 1) || !(a->KW & 1)) return EVC_EINVAL;
     if (a->ld_out < a->Co || (a->res && a->ld_res < a->Co)) return EVC_EINVAL;
     if ((long long)a->B * a->H * a->W > 0x7fffffffLL) return EVC_EINVAL;
-    if (a->arith != EVC_ARITH_F32 && a->arith != EVC_ARITH_BF16X6) return EVC_EINVAL;
+    if (a->arith != EVC_ARITH_F32 && a->arith != EVC_ARITH_BF16X6 && a->arith != EVC_ARITH_F16X3) return EVC_EINVAL;
     return EVC_OK;
 }
 
@@ -1937,6 +1432,13 @@ static void split_tile_cfg(const evc_conv_args* a, long long M, long long ntile,
     c.splits = best_s;
 }
 
+static inline bool is_split_arith(int arith) { return arith == EVC_ARITH_BF16X6 || arith == EVC_ARITH_F16X3; }
+static inline int arith_planes(int arith) { return arith == EVC_ARITH_F16X3 ? 2 : 3; }
+constexpr long long LDS_CAP = 160 * 1024;     // gfx950: 160 KiB per CU, one workgroup may take all of it
+
+// dynamic LDS of the row-reuse kernel: 2 buffers x NP planes x (staged activation rows + weight rows) x 32 B
+static long long rr_lds_bytes(int np, int bm, int W, int bn) { return 2LL * np * ((long long)(bm / W) * (W + 2) + bn) * 32; }
+
 static TileCfg conv_tile_cfg(const evc_conv_args* a) {
     TileCfg c;
     const long long M = (long long)a->B * a->H * a->W;
@@ -1946,22 +1448,22 @@ static TileCfg conv_tile_cfg(const evc_conv_args* a) {
     const long long ntile = CoPad / c.bn;
     const int nsteps = a->KH * a->KW * ((a->C0 + a->C1) / KC);
     c.reuse = 0;
-    if (a->arith == EVC_ARITH_BF16X6) {
+    if (is_split_arith(a->arith)) {
+        const int np = arith_planes(a->arith);
         split_tile_cfg(a, M, ntile, nsteps, c);
-#if EVC_SPLIT_ROWREUSE
-        // row-reuse kernel: 3x3 filters, 128-pixel tiles made of whole image rows
-        if (!g_no_reuse && a->KH == 3 && a->KW == 3 && c.tm == 2 && a->W >= 4 && 128 % a->W == 0) c.reuse = 1;
+        // row-reuse kernel: 3x3 filters, 128-pixel tiles made of whole image rows (and an LDS image that fits: W >= 4)
+        if (!g_no_reuse && a->KH == 3 && a->KW == 3 && c.tm == 2 && a->W >= 4 && 128 % a->W == 0 &&
+            rr_lds_bytes(np, 128, a->W, c.bn) <= LDS_CAP) c.reuse = 1;
         // 8-wave / 256-pixel form of the row-reuse kernel (one workgroup per CU = 256 slots).  Measured (B=8, 128x128:
         // exactly 2 rounds) +4-5 %; at B=9 (2.25 rounds) -5 %: the coarser tile makes the tail worse.  So: unsplit
         // grids that are a whole number of >= 2 rounds, or long enough (>= 6 rounds) for the tail not to matter.
-        if (c.reuse && c.splits == 1 && g_wide_tiles && M % 256 == 0) {
+        if (c.reuse && c.splits == 1 && g_wide_tiles && M % 256 == 0 && rr_lds_bytes(np, 256, a->W, c.bn) <= LDS_CAP) {
             const long long t256 = (M / 256) * ntile;
             if ((t256 >= 512 && t256 % 256 == 0) || t256 >= 6 * 256) {
                 c.bm = 256;
                 c.tiles = t256;
             }
         }
-#endif
     } else {
         c.tm = (!EVC_CONV_TM1 || ((M + 127) / 128) * ntile >= 64) ? 2 : 1;
         if (g_force_tm) c.tm = g_force_tm;
@@ -1977,15 +1479,9 @@ static TileCfg conv_tile_cfg(const evc_conv_args* a) {
             if (splits < 1) splits = 1;
         }
         c.splits = (int)splits;
-        // Row-reuse kernel: multi-tap filters whose tiles are whole image rows; a split must cover whole chunks, so
-        // round the steps per split up to a multiple of the tap count (the effective split count may shrink).
-#if EVC_CONV_ROWREUSE
-        const int taps = a->KH * a->KW;
-        if (taps > 1 && a->KH <= 3 && a->KW <= 3 && c.bm % a->W == 0) c.reuse = 1;
-#endif
     }
-    // splits of the row-reuse kernels cover whole (chunk, kernel row) groups (bf16x6: 3 taps) / whole chunks (f32: 9 taps)
-    const int unit = c.reuse ? (a->arith == EVC_ARITH_BF16X6 ? a->KW : a->KH * a->KW) : 1;
+    // splits of the row-reuse kernel cover whole (chunk, kernel row) groups: 3 taps
+    const int unit = c.reuse ? a->KW : 1;
     int sps = (nsteps + c.splits - 1) / c.splits;
     sps = (sps + unit - 1) / unit * unit;
     c.steps_per_split = sps;
@@ -2017,100 +1513,73 @@ extern "C" long long evc_conv_workspace_bytes(const evc_conv_args* a) {
     return (long long)s * a->B * a->H * a->W * a->Co * (long long)sizeof(float);
 }
 
-template <int TM, int TN>
-static void launch_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
-    switch (mode) {
-        case MODE_AFFINE: hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, MODE_AFFINE>), grid, dim3(256), lds, st, k); break;
-        case MODE_AFFINE_SILU: hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, MODE_AFFINE_SILU>), grid, dim3(256), lds, st, k); break;
-        case MODE_SILU: hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, MODE_SILU>), grid, dim3(256), lds, st, k); break;
-        case MODE_RELU: hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, MODE_RELU>), grid, dim3(256), lds, st, k); break;
-        default: hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, MODE_PLAIN>), grid, dim3(256), lds, st, k); break;
-    }
+// Kernels that take more than the default 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised,
+// once per (kernel instantiation, device): a bit per device id, set only after the call succeeded.
+static int ensure_dynamic_lds(const void* fn, unsigned long long* done_mask, size_t lds) {
+    if (lds <= 64 * 1024) return EVC_OK;
+    if ((long long)lds > LDS_CAP) return EVC_EUNSUPPORTED;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return EVC_ELAUNCH;
+    const unsigned long long bit = 1ULL << (dev & 63);
+    if (__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) & bit) return EVC_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP) != hipSuccess) return EVC_ELAUNCH;
+    __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
+    return EVC_OK;
 }
+
+#define EVC_MODE_SWITCH(mode, CALL)                                   \
+    switch (mode) {                                                   \
+        case MODE_AFFINE: CALL(MODE_AFFINE); break;                   \
+        case MODE_AFFINE_SILU: CALL(MODE_AFFINE_SILU); break;         \
+        case MODE_SILU: CALL(MODE_SILU); break;                       \
+        case MODE_RELU: CALL(MODE_RELU); break;                       \
+        default: CALL(MODE_PLAIN); break;                             \
+    }
 
 template <int TM, int TN>
-static void launch_split(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
-    switch (mode) {
-        case MODE_AFFINE: hipLaunchKernelGGL((conv_split_kernel<TM, TN, MODE_AFFINE>), grid, dim3(256), lds, st, k); break;
-        case MODE_AFFINE_SILU: hipLaunchKernelGGL((conv_split_kernel<TM, TN, MODE_AFFINE_SILU>), grid, dim3(256), lds, st, k); break;
-        case MODE_SILU: hipLaunchKernelGGL((conv_split_kernel<TM, TN, MODE_SILU>), grid, dim3(256), lds, st, k); break;
-        case MODE_RELU: hipLaunchKernelGGL((conv_split_kernel<TM, TN, MODE_RELU>), grid, dim3(256), lds, st, k); break;
-        default: hipLaunchKernelGGL((conv_split_kernel<TM, TN, MODE_PLAIN>), grid, dim3(256), lds, st, k); break;
-    }
+static int launch_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+#define EVC_CALL(M) hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, M>), grid, dim3(256), lds, st, k)
+    EVC_MODE_SWITCH(mode, EVC_CALL)
+#undef EVC_CALL
+    return EVC_OK;
 }
 
-#if EVC_SPLIT_ROWREUSE
-template <int WM, int TN, int MODE>
-static void launch_split_rr_one(dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
-    static bool attr_set = false;      // init-once: up to 68 KB (WM = 2, W = 8) / 96 KB (WM = 4) of dynamic LDS
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_rr_kernel<WM, TN, MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (WM == 2 ? 72 : 104) * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((conv_split_rr_kernel<WM, TN, MODE>), grid, dim3(128 * WM), lds, st, k);
-}
-template <int WM, int TN>
-static void launch_split_rr(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
-    switch (mode) {
-        case MODE_AFFINE: launch_split_rr_one<WM, TN, MODE_AFFINE>(grid, lds, st, k); break;
-        case MODE_AFFINE_SILU: launch_split_rr_one<WM, TN, MODE_AFFINE_SILU>(grid, lds, st, k); break;
-        case MODE_SILU: launch_split_rr_one<WM, TN, MODE_SILU>(grid, lds, st, k); break;
-        case MODE_RELU: launch_split_rr_one<WM, TN, MODE_RELU>(grid, lds, st, k); break;
-        default: launch_split_rr_one<WM, TN, MODE_PLAIN>(grid, lds, st, k); break;
-    }
-}
-#endif
-
-#if EVC_SPLIT_PC
-template <int TN, int MODE>
-static void launch_split_pc_one(dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
-    static bool attr_set = false;      // init-once: allow > 64 KB of dynamic LDS for this instantiation
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_pc_kernel<TN, MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((conv_split_pc_kernel<TN, MODE>), grid, dim3(512), lds, st, k);
-}
-template <int TN>
-static void launch_split_pc(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
-    switch (mode) {
-        case MODE_AFFINE: launch_split_pc_one<TN, MODE_AFFINE>(grid, lds, st, k); break;
-        case MODE_AFFINE_SILU: launch_split_pc_one<TN, MODE_AFFINE_SILU>(grid, lds, st, k); break;
-        case MODE_SILU: launch_split_pc_one<TN, MODE_SILU>(grid, lds, st, k); break;
-        case MODE_RELU: launch_split_pc_one<TN, MODE_RELU>(grid, lds, st, k); break;
-        default: launch_split_pc_one<TN, MODE_PLAIN>(grid, lds, st, k); break;
-    }
-}
-#endif
-
-#if EVC_CONV_PC
-template <int TN>
-static void launch_pc(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
-    switch (mode) {
-        case MODE_AFFINE: hipLaunchKernelGGL((conv_pc_kernel<TN, MODE_AFFINE>), grid, dim3(512), lds, st, k); break;
-        case MODE_AFFINE_SILU: hipLaunchKernelGGL((conv_pc_kernel<TN, MODE_AFFINE_SILU>), grid, dim3(512), lds, st, k); break;
-        case MODE_SILU: hipLaunchKernelGGL((conv_pc_kernel<TN, MODE_SILU>), grid, dim3(512), lds, st, k); break;
-        case MODE_RELU: hipLaunchKernelGGL((conv_pc_kernel<TN, MODE_RELU>), grid, dim3(512), lds, st, k); break;
-        default: hipLaunchKernelGGL((conv_pc_kernel<TN, MODE_PLAIN>), grid, dim3(512), lds, st, k); break;
-    }
-}
-#endif
-
-#if EVC_CONV_ROWREUSE
+// bf16x6 off the row-reuse path: the software-pipelined kernel
 template <int TM, int TN>
-static void launch_reuse(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
-    switch (mode) {
-        case MODE_AFFINE: hipLaunchKernelGGL((conv_rowreuse_kernel<TM, TN, MODE_AFFINE>), grid, dim3(256), lds, st, k); break;
-        case MODE_AFFINE_SILU: hipLaunchKernelGGL((conv_rowreuse_kernel<TM, TN, MODE_AFFINE_SILU>), grid, dim3(256), lds, st, k); break;
-        case MODE_SILU: hipLaunchKernelGGL((conv_rowreuse_kernel<TM, TN, MODE_SILU>), grid, dim3(256), lds, st, k); break;
-        case MODE_RELU: hipLaunchKernelGGL((conv_rowreuse_kernel<TM, TN, MODE_RELU>), grid, dim3(256), lds, st, k); break;
-        default: hipLaunchKernelGGL((conv_rowreuse_kernel<TM, TN, MODE_PLAIN>), grid, dim3(256), lds, st, k); break;
-    }
+static int launch_split3(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+#define EVC_CALL(M) hipLaunchKernelGGL((conv_split_kernel<TM, TN, M>), grid, dim3(256), lds, st, k)
+    EVC_MODE_SWITCH(mode, EVC_CALL)
+#undef EVC_CALL
+    return EVC_OK;
 }
 
-#endif
+// f16x3 off the row-reuse path: the simple-schedule kernel
+template <int TM, int TN>
+static int launch_split2(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+#define EVC_CALL(M) hipLaunchKernelGGL((conv_splitn_kernel<2, TM, TN, M>), grid, dim3(256), lds, st, k)
+    EVC_MODE_SWITCH(mode, EVC_CALL)
+#undef EVC_CALL
+    return EVC_OK;
+}
+
+template <int NP, int WM, int TN, int MODE>
+static int launch_split_rr_one(dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+    static unsigned long long attr_done = 0;
+    const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_split_rr_kernel<NP, WM, TN, MODE>), &attr_done, lds);
+    if (rc != EVC_OK) return rc;
+    hipLaunchKernelGGL((conv_split_rr_kernel<NP, WM, TN, MODE>), grid, dim3(128 * WM), lds, st, k);
+    return EVC_OK;
+}
+template <int NP, int WM, int TN>
+static int launch_split_rr(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+    int rc = EVC_OK;
+#define EVC_CALL(M) rc = launch_split_rr_one<NP, WM, TN, M>(grid, lds, st, k)
+    EVC_MODE_SWITCH(mode, EVC_CALL)
+#undef EVC_CALL
+    return rc;
+}
+
+#define EVC_TN_SWITCH(tn, CALL) ((tn) == 3 ? CALL(3) : (tn) == 2 ? CALL(2) : CALL(1))
 
 extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stream) {
     int rc = conv_validate(a);
@@ -2129,6 +1598,11 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     k.ld0 = a->ld0 > 0 ? a->ld0 : a->C0; k.ld1 = a->ld1 > 0 ? a->ld1 : (a->C1 > 0 ? a->C1 : k.ld0);
     k.coef_a = a->coef_a; k.coef_s = a->coef_s;
     k.w = a->w_packed; k.bias = a->bias; k.res = a->res; k.ld_res = a->ld_res;
+    k.w_hdr = nullptr;
+    if (a->arith == EVC_ARITH_F16X3) {     // [header][planes]
+        k.w_hdr = a->w_packed;
+        k.w = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a->w_packed) + F16_HDR_BYTES);
+    }
     k.out_scale = a->out_scale; k.act_out = a->act_out; k.out = a->out; k.ld_out = a->ld_out;
     k.B = a->B; k.H = a->H; k.W = a->W; k.Co = a->Co; k.CoPad = evc_conv_co_pad(a->Co);
     k.KH = a->KH; k.KW = a->KW;
@@ -2148,74 +1622,42 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
 
     dim3 grid((k.M + cfg.bm - 1) / cfg.bm, k.CoPad / cfg.bn, k.splits);
     hipStream_t st = (hipStream_t)stream;
-    if (a->arith == EVC_ARITH_BF16X6) {
-        const size_t lds = (size_t)2 * 3 * (cfg.bm + cfg.bn) * 32;
-#if EVC_SPLIT_ROWREUSE
+    if (is_split_arith(a->arith)) {
+        const int np = arith_planes(a->arith);
         if (cfg.reuse) {
-            const size_t lds_rr = (size_t)2 * 3 * ((cfg.bm / a->W) * (a->W + 2) + cfg.bn) * 32;
-            if (cfg.bm == 256) {
-                if (cfg.tn == 3) launch_split_rr<4, 3>(mode, grid, lds_rr, st, k);
-                else if (cfg.tn == 2) launch_split_rr<4, 2>(mode, grid, lds_rr, st, k);
-                else launch_split_rr<4, 1>(mode, grid, lds_rr, st, k);
-            } else {
-                if (cfg.tn == 3) launch_split_rr<2, 3>(mode, grid, lds_rr, st, k);
-                else if (cfg.tn == 2) launch_split_rr<2, 2>(mode, grid, lds_rr, st, k);
-                else launch_split_rr<2, 1>(mode, grid, lds_rr, st, k);
-            }
-        } else
-#endif
-#if EVC_SPLIT_PC
-        if (cfg.tm == 2) {
-            const size_t lds_pc = (size_t)5 * 3 * (cfg.bm + cfg.bn) * 32;
-            if (cfg.tn == 3) launch_split_pc<3>(mode, grid, lds_pc, st, k);
-            else if (cfg.tn == 2) launch_split_pc<2>(mode, grid, lds_pc, st, k);
-            else launch_split_pc<1>(mode, grid, lds_pc, st, k);
-        } else
-#endif
-        if (cfg.tm == 2) {
-            if (cfg.tn == 3) launch_split<2, 3>(mode, grid, lds, st, k);
-            else if (cfg.tn == 2) launch_split<2, 2>(mode, grid, lds, st, k);
-            else launch_split<2, 1>(mode, grid, lds, st, k);
+            const size_t lds_rr = (size_t)rr_lds_bytes(np, cfg.bm, a->W, cfg.bn);
+#define EVC_RR4_3(TN) launch_split_rr<3, 4, TN>(mode, grid, lds_rr, st, k)
+#define EVC_RR2_3(TN) launch_split_rr<3, 2, TN>(mode, grid, lds_rr, st, k)
+#define EVC_RR4_2(TN) launch_split_rr<2, 4, TN>(mode, grid, lds_rr, st, k)
+#define EVC_RR2_2(TN) launch_split_rr<2, 2, TN>(mode, grid, lds_rr, st, k)
+            if (np == 3) rc = cfg.bm == 256 ? EVC_TN_SWITCH(cfg.tn, EVC_RR4_3) : EVC_TN_SWITCH(cfg.tn, EVC_RR2_3);
+            else rc = cfg.bm == 256 ? EVC_TN_SWITCH(cfg.tn, EVC_RR4_2) : EVC_TN_SWITCH(cfg.tn, EVC_RR2_2);
+#undef EVC_RR4_3
+#undef EVC_RR2_3
+#undef EVC_RR4_2
+#undef EVC_RR2_2
         } else {
-            if (cfg.tn == 3) launch_split<1, 3>(mode, grid, lds, st, k);
-            else if (cfg.tn == 2) launch_split<1, 2>(mode, grid, lds, st, k);
-            else launch_split<1, 1>(mode, grid, lds, st, k);
+            const size_t lds = (size_t)2 * np * (cfg.bm + cfg.bn) * 32;
+#define EVC_S3_2(TN) launch_split3<2, TN>(mode, grid, lds, st, k)
+#define EVC_S3_1(TN) launch_split3<1, TN>(mode, grid, lds, st, k)
+#define EVC_S2_2(TN) launch_split2<2, TN>(mode, grid, lds, st, k)
+#define EVC_S2_1(TN) launch_split2<1, TN>(mode, grid, lds, st, k)
+            if (np == 3) rc = cfg.tm == 2 ? EVC_TN_SWITCH(cfg.tn, EVC_S3_2) : EVC_TN_SWITCH(cfg.tn, EVC_S3_1);
+            else rc = cfg.tm == 2 ? EVC_TN_SWITCH(cfg.tn, EVC_S2_2) : EVC_TN_SWITCH(cfg.tn, EVC_S2_1);
+#undef EVC_S3_2
+#undef EVC_S3_1
+#undef EVC_S2_2
+#undef EVC_S2_1
         }
-    } else
-#if EVC_CONV_PC
-    if (cfg.tm == 2) {
+    } else {
         const size_t lds = (size_t)2 * (cfg.bm + cfg.bn) * KC * sizeof(float);
-        if (cfg.tn == 3) launch_pc<3>(mode, grid, lds, st, k);
-        else if (cfg.tn == 2) launch_pc<2>(mode, grid, lds, st, k);
-        else launch_pc<1>(mode, grid, lds, st, k);
-    } else
-#endif
-#if EVC_CONV_ROWREUSE
-    if (cfg.reuse) {
-        const size_t lds = (size_t)2 * (a->KH * (cfg.bm + 2 * (a->KW / 2)) + cfg.bn) * KC * sizeof(float);
-        if (cfg.tm == 2) {
-            if (cfg.tn == 3) launch_reuse<2, 3>(mode, grid, lds, st, k);
-            else if (cfg.tn == 2) launch_reuse<2, 2>(mode, grid, lds, st, k);
-            else launch_reuse<2, 1>(mode, grid, lds, st, k);
-        } else {
-            if (cfg.tn == 3) launch_reuse<1, 3>(mode, grid, lds, st, k);
-            else if (cfg.tn == 2) launch_reuse<1, 2>(mode, grid, lds, st, k);
-            else launch_reuse<1, 1>(mode, grid, lds, st, k);
-        }
-    } else
-#endif
-    {
-        const size_t lds = (size_t)2 * (cfg.bm + cfg.bn) * KC * sizeof(float);
-        if (cfg.tm == 2) {
-            if (cfg.tn == 3) launch_mode<2, 3>(mode, grid, lds, st, k);
-            else if (cfg.tn == 2) launch_mode<2, 2>(mode, grid, lds, st, k);
-            else launch_mode<2, 1>(mode, grid, lds, st, k);
-        } else {
-            if (cfg.tn == 3) launch_mode<1, 3>(mode, grid, lds, st, k);
-            else if (cfg.tn == 2) launch_mode<1, 2>(mode, grid, lds, st, k);
-            else launch_mode<1, 1>(mode, grid, lds, st, k);
-        }
+#define EVC_F_2(TN) launch_mode<2, TN>(mode, grid, lds, st, k)
+#define EVC_F_1(TN) launch_mode<1, TN>(mode, grid, lds, st, k)
+        rc = cfg.tm == 2 ? EVC_TN_SWITCH(cfg.tn, EVC_F_2) : EVC_TN_SWITCH(cfg.tn, EVC_F_1);
+#undef EVC_F_2
+#undef EVC_F_1
     }
+    if (rc != EVC_OK) return rc;
     if (hipGetLastError() != hipSuccess) return EVC_ELAUNCH;
     if (k.splits > 1) {
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((k.M + 63) / 64, (k.Co + 63) / 64), dim3(1024), 0, st, ws,

@@ -68,10 +68,10 @@ class ClipDecoder:
             bounds = [(g * B // groups, (g + 1) * B // groups) for g in range(groups)]
             main = torch.cuda.current_stream()
             streams = self._streams(groups)
-            if hasattr(self.net, "prepare_labels"):   # table rows are shared state: build them once, up front
-                n = kw["subsample_steps"] or len(self.net.betas)
-                skip = max(1, len(self.net.betas) // n)
-                self.net.prepare_labels([float(v) for v in range(0, len(self.net.betas), skip)] + [float(n - 1)])
+            if hasattr(self.net, "prepare_labels"):
+                # AdaGN table rows are shared state: build every row this sampler will read (F-PNDM: incl. the
+                # Runge-Kutta midpoints and -1) on the main stream, which all group streams wait on below
+                self.net.prepare_labels(S.label_set(self.sampler, self.net, kw["subsample_steps"], kw["denoise"]))
             gens = []
             for (lo, hi), st in zip(bounds, streams):
                 st.wait_stream(main)

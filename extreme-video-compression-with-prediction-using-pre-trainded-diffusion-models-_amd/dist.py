@@ -6,9 +6,35 @@ exchanged inside a clip.  So the only collective on the path is ONE broadcast of
 at start-up (RCCL over xGMI: backend "nccl" on ROCm) and an optional gather of per-clip results.
 """
 import os
+import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
+
+
+def needs_self_launch(n_ranks):
+    """True when a script was asked for ``n_ranks`` > 1 but runs outside a torchrun environment."""
+    return n_ranks > 1 and "WORLD_SIZE" not in os.environ
+
+
+def self_launch(script, argv, n_ranks, timeout=None):
+    """Start ``n_ranks`` fresh ranks of ``script argv`` (``python -m torch.distributed.run``, one process per GPU,
+    rendezvous on 127.0.0.1 and a free port) as CHILD processes and return the launcher's exit code.
+
+    Must be called before the calling process makes any HIP call: the parent never touches the GPU (on this pool a
+    process that has initialised the GPU must not exec or be replaced), it only relays the children's output --
+    rank 0 prints the result line -- and their exit status (non-zero if any rank failed)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: required by RCCL on this driver
+    env["EVC_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    return subprocess.run(cmd, env=env, timeout=timeout).returncode
 
 
 def init(backend=None):
@@ -81,6 +107,14 @@ def broadcast_state_dict(sd, src=0, device=None, world=None):
             dist.broadcast(t, src=src)
             out[k] = t
     return out
+
+
+def backend_name():
+    """"nccl" is RCCL on ROCm (collectives over xGMI); "gloo" in CPU rehearsals; "none" for a single process."""
+    if not dist.is_initialized():
+        return "none"
+    b = dist.get_backend()
+    return "nccl (RCCL)" if b == "nccl" else str(b)
 
 
 def barrier():

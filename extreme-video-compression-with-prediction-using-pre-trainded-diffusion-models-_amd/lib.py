@@ -16,19 +16,35 @@ HIP_SO = os.path.join(HERE, "lib", "libevc_hip.so")
 RANS_SO = os.path.join(HERE, "lib", "libevc_rans.so")
 
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
-# How the convolution multiplies (include/evc_hip.h EVC_ARITH_*).  Both are fp32 convolutions with fp32 accumulation;
-# BF16X6 splits every fp32 operand exactly into three bf16 values and runs the six significant cross products on the
-# bf16 matrix cores (measured error vs fp64: equal to or below the f32 MFMA chain).  The packed weights carry the
-# choice in their dtype (float32 / bfloat16).  EVC_CONV_ARITH=f32|bf16x6 overrides the default.
-ARITH_F32, ARITH_BF16X6 = 0, 1
-_ARITH_NAMES = {"f32": ARITH_F32, "bf16x6": ARITH_BF16X6}
+# How the convolution multiplies (include/evc_hip.h EVC_ARITH_*).  All are fp32 convolutions with fp32 accumulation:
+#   F32     v_mfma_f32_32x32x2_f32, exact products;
+#   BF16X6  every fp32 operand split exactly into three bf16 values, six cross products on the bf16 matrix cores;
+#   F16X3   operands scaled into fp16's range and split 2-way (2^-22 relative), three cross products on the fp16 matrix
+#           cores -- only valid where the operand is O(1) (GroupNorm-normalised / activated inputs).
+# Measured error vs fp64 on MI355X: F16X3 < BF16X6 < F32 chain (profiles/r02_split_numerics.log).  The packed weights
+# carry the choice in their dtype (float32 / bfloat16 / float16).  EVC_CONV_ARITH=f32|bf16x6|f16x3 sets the policy:
+# "f16x3" (default) = F16X3 for convolutions whose input is normalised (``bounded_arith``), BF16X6 for the rest.
+ARITH_F32, ARITH_BF16X6, ARITH_F16X3 = 0, 1, 2
+_ARITH_NAMES = {"f32": ARITH_F32, "bf16x6": ARITH_BF16X6, "f16x3": ARITH_F16X3}
+_ARITH_DTYPES = {ARITH_F32: torch.float32, ARITH_BF16X6: torch.bfloat16, ARITH_F16X3: torch.float16}
 
 
-def default_arith():
-    name = os.environ.get("EVC_CONV_ARITH", "bf16x6").lower()
+def _arith_policy():
+    name = os.environ.get("EVC_CONV_ARITH", "f16x3").lower()
     if name not in _ARITH_NAMES:
         raise ValueError(f"EVC_CONV_ARITH must be one of {sorted(_ARITH_NAMES)}, got {name!r}")
     return _ARITH_NAMES[name]
+
+
+def default_arith():
+    """Arithmetic for convolutions whose operand range is unknown (raw residual streams, ELIC): never F16X3."""
+    a = _arith_policy()
+    return ARITH_BF16X6 if a == ARITH_F16X3 else a
+
+
+def bounded_arith():
+    """Arithmetic for convolutions whose input is GroupNorm-normalised / activated, i.e. O(1)."""
+    return _arith_policy()
 
 
 class EvcLibraryError(RuntimeError):
@@ -283,7 +299,8 @@ def affine_act(x, coef, act, out=None, coef_col=0):
 
 def conv_pack_weights(w, arith=None):
     """w: (Co, Ci, KH, KW) device float32 with Ci % 16 == 0 -> packed flat tensor: float32 for ARITH_F32, bfloat16
-    (three planes) for ARITH_BF16X6; ``conv2d_nhwc`` picks the kernel from that dtype."""
+    (three planes) for ARITH_BF16X6, float16 (header + two planes) for ARITH_F16X3; ``conv2d_nhwc`` picks the kernel
+    from that dtype."""
     L = hip_lib()
     arith = default_arith() if arith is None else arith
     w = w.contiguous()
@@ -291,16 +308,16 @@ def conv_pack_weights(w, arith=None):
     nbytes = L.evc_conv_packed_bytes(Co, Ci, KH, KW, arith)
     if nbytes < 0:
         raise EvcKernelError(f"evc_conv_packed_bytes rejected the arguments ({nbytes})")
-    if arith == ARITH_BF16X6:
-        packed = torch.empty((nbytes // 2,), device=w.device, dtype=torch.bfloat16)
-    else:
-        packed = torch.empty((nbytes // 4,), device=w.device, dtype=torch.float32)
+    if arith not in _ARITH_DTYPES:
+        raise EvcKernelError(f"unknown convolution arithmetic {arith}")
+    dt = _ARITH_DTYPES[arith]
+    packed = torch.empty((nbytes // dt.itemsize,), device=w.device, dtype=dt)
     _check(L.evc_conv_pack_weights(fptr(w), ptr(packed), Co, Ci, KH, KW, arith, stream_ptr()), "evc_conv_pack_weights")
     return packed
 
 
 def packed_arith(w_packed):
-    return ARITH_BF16X6 if w_packed.dtype == torch.bfloat16 else ARITH_F32
+    return {torch.bfloat16: ARITH_BF16X6, torch.float16: ARITH_F16X3}.get(w_packed.dtype, ARITH_F32)
 
 
 _ws_cache = {}

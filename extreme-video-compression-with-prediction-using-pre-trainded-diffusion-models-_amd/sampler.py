@@ -179,10 +179,7 @@ def fpndm_steps(x_mod, scorenet, cond=None, final_only=False, denoise=True, subs
     skip = len(alphas_old) // subsample_steps
     steps = list(range(0, len(alphas_old), skip))
     steps_next = [-1] + steps[:-1]
-    labels = set()
-    for t, tn in zip(steps, steps_next):
-        labels.update([float(t), (t + tn) / 2, float(tn)])
-    _prepare(net, sorted(labels))
+    _prepare(net, fpndm_labels(len(alphas_old), subsample_steps))
     x = x_mod.detach().to(torch.float32).clone().contiguous()
     ets, images = [], []
     for t, tn in zip(steps, steps_next):
@@ -208,7 +205,31 @@ def fpndm_steps(x_mod, scorenet, cond=None, final_only=False, denoise=True, subs
     return x.unsqueeze(0) if final_only else torch.stack(images)
 
 
-STEP_GENERATORS = {}
+def fpndm_labels(n_classes, subsample_steps):
+    """Every label F-PNDM passes to the network: the step values, the Runge-Kutta midpoints of the first three
+    iterations and -1 (models/__init__.py:59-92, models/pndm.py:3-17)."""
+    skip = n_classes // subsample_steps
+    steps = list(range(0, n_classes, skip))
+    steps_next = [-1] + steps[:-1]
+    labels = set()
+    for i, (t, tn) in enumerate(zip(steps, steps_next)):
+        labels.add(float(t))
+        if i < 3:
+            labels.update([(t + tn) / 2, float(tn)])
+    return sorted(labels)
+
+
+def label_set(sampler_fn, scorenet, subsample_steps=None, denoise=True):
+    """The exact set of network labels ``sampler_fn`` will use.  ``ClipDecoder.generate`` evaluates their AdaGN
+    table rows on the main stream BEFORE clip groups fan out to their own streams (the table is shared state; a
+    row built lazily on one group's stream would be read by the others with no ordering)."""
+    net = _net(scorenet)
+    n = len(net.betas)
+    if sampler_fn is FPNDM_sampler:
+        return fpndm_labels(n, subsample_steps or n)
+    steps, _, _, _ = _subsample(net, subsample_steps)
+    return [float(v) for v in steps] + ([float(len(steps) - 1)] if denoise else [])
+
 
 
 def get_step_generator(sampler_fn):

@@ -148,13 +148,15 @@ class ScoreNet:
     def _dev(self, t):
         return t.detach().to(device=self.device, dtype=torch.float32).contiguous()
 
-    def _pack_conv(self, w, pad_ci=None):
+    def _pack_conv(self, w, pad_ci=None, bounded=False):
+        """``bounded``: the convolution's input is GroupNorm-normalised / activated (O(1)), so the fp16-split
+        arithmetic applies; raw residual-stream inputs keep the bf16 split (no range assumption)."""
         w = self._dev(w)
         if pad_ci is not None and pad_ci != w.shape[1]:
             wp = torch.zeros((w.shape[0], pad_ci, w.shape[2], w.shape[3]), device=self.device)
             wp[:, :w.shape[1]] = w
             w = wp
-        return L.conv_pack_weights(w)
+        return L.conv_pack_weights(w, L.bounded_arith() if bounded else L.default_arith())
 
     def _load(self, sd, pre):
         g = lambda name: sd[name]
@@ -169,8 +171,9 @@ class ScoreNet:
                 self.w[i] = dict(w=self._pack_conv(w[:, :, None, None]), b=self._dev(g(n + ".bias")),
                                  co=w.shape[0])
             elif k in ("conv_in", "conv_out"):
-                w = g(n + ".weight")
-                self.w[i] = dict(w=self._pack_conv(w, _pad16(w.shape[1])), b=self._dev(g(n + ".bias")),
+                w = g(n + ".weight")     # conv_out reads the final GroupNorm + SiLU; conv_in the raw network input
+                self.w[i] = dict(w=self._pack_conv(w, _pad16(w.shape[1]), bounded=(k == "conv_out")),
+                                 b=self._dev(g(n + ".bias")),
                                  co=w.shape[0], cin_pad=_pad16(w.shape[1]))
             elif k == "res":
                 e = dict()
@@ -179,8 +182,9 @@ class ScoreNet:
                     dense_w.append(dw); dense_b.append(db)
                     e[f"ss{j}"] = (off, dw.shape[0] // 2)
                     off += dw.shape[0]
-                e["w0"] = self._pack_conv(g(n + ".Conv_0.weight")); e["b0"] = self._dev(g(n + ".Conv_0.bias"))
-                e["w1"] = self._pack_conv(g(n + ".Conv_1.weight")); e["b1"] = self._dev(g(n + ".Conv_1.bias"))
+                # Conv_0 / Conv_1 read AdaGN + SiLU outputs (directly or through the FIR resampler): O(1) operands
+                e["w0"] = self._pack_conv(g(n + ".Conv_0.weight"), bounded=True); e["b0"] = self._dev(g(n + ".Conv_0.bias"))
+                e["w1"] = self._pack_conv(g(n + ".Conv_1.weight"), bounded=True); e["b1"] = self._dev(g(n + ".Conv_1.bias"))
                 if m["cin"] != m["cout"] or m["up"] or m["down"]:
                     e["w2"] = self._pack_conv(g(n + ".Conv_2.weight")); e["b2"] = self._dev(g(n + ".Conv_2.bias"))
                 self.w[i] = e
@@ -190,7 +194,8 @@ class ScoreNet:
                 wqkv = torch.cat([w.t() for w in ws[:3]], 0)[:, :, None, None]
                 self.w[i] = dict(gamma=self._dev(g(n + ".GroupNorm_0.weight")),
                                  beta=self._dev(g(n + ".GroupNorm_0.bias")),
-                                 wqkv=self._pack_conv(wqkv), bqkv=self._dev(torch.cat(bs[:3], 0)),
+                                 wqkv=self._pack_conv(wqkv, bounded=True),     # input: affine GroupNorm
+                                 bqkv=self._dev(torch.cat(bs[:3], 0)),
                                  wo=self._pack_conv(ws[3].t()[:, :, None, None]), bo=self._dev(bs[3]))
             elif k == "norm":
                 self.w[i] = dict(gamma=self._dev(g(n + ".Norm_0.weight")), beta=self._dev(g(n + ".Norm_0.bias")))

@@ -32,6 +32,15 @@ extern "C" {
  *                     that of EVC_ARITH_F32 (tools/split_numerics.hip). */
 #define EVC_ARITH_F32 0
 #define EVC_ARITH_BF16X6 1
+/*   EVC_ARITH_F16X3   both operands are scaled by powers of two into fp16's range (weights per tensor at pack time,
+ *                     activations by 8 with saturation at +-65504), split 2-way into fp16 (11 + 11 significand bits,
+ *                     2^-22 relative) and three cross products run on v_mfma_f32_32x32x16_f16 (bf16 rate); the exact
+ *                     inverse scale is applied to the fp32 accumulator.  Half the MFMAs and two thirds of the LDS
+ *                     bytes of BF16X6.  Measured error against fp64: BELOW both F32 and BF16X6 for O(1) operands
+ *                     (profiles/r02_split_numerics.log) -- fewer accumulator roundings -- but operands spanning more
+ *                     than fp16's exponent range are NOT representable: use it only where the input is
+ *                     GroupNorm-normalised / activated (the caller's choice, made when packing the weights). */
+#define EVC_ARITH_F16X3 2
 
 /* Library / device identification. evc_arch() returns the gfx target the code object was built
  * for ("gfx950"). evc_device_ok() returns 1 when the current HIP device can run it. */
@@ -119,8 +128,9 @@ int evc_conv_co_pad(int Co);
 long long evc_conv_packed_floats(int Co, int Ci, int KH, int KW);
 /* w: [Co][Ci][KH][KW] (PyTorch Conv2d layout, device) -> packed (device). */
 int evc_conv_pack_weights_f32(const float* w, float* packed, int Co, int Ci, int KH, int KW, void* stream);
-/* The same for either arithmetic: EVC_ARITH_F32 -> the layout above (4 bytes per element), EVC_ARITH_BF16X6 ->
- * [KH*KW][Ci/16][3 planes][CoPad][16 bf16] (6 bytes per element). */
+/* The same for any arithmetic: EVC_ARITH_F32 -> the layout above (4 bytes per element), EVC_ARITH_BF16X6 ->
+ * [KH*KW][Ci/16][3 planes][CoPad][16 bf16] (6 bytes per element), EVC_ARITH_F16X3 -> a 256-byte header (inverse
+ * accumulator scale, weight scale) + [KH*KW][Ci/16][2 planes][CoPad][16 fp16] (4 bytes per element). */
 long long evc_conv_packed_bytes(int Co, int Ci, int KH, int KW, int arith);
 int evc_conv_pack_weights(const float* w, void* packed, int Co, int Ci, int KH, int KW, int arith, void* stream);
 int evc_conv_choose_splits(const evc_conv_args* a);

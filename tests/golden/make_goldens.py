@@ -185,16 +185,55 @@ def gen_forward_full():
          first_row=o[0, :, 0, :].clone())
 
 
+def gen_forward_full_b9():
+    """BASELINE configs[1] launches the score network at B=9 (configs[4] at B=32): nine differently seeded samples
+    through the full-size reference in one batch at the DDPM label 500, the first two also at the fractional
+    F-PNDM label -0.5 and the denoise label 99.  The GPU tests run them as ONE B=9 launch (and cycled to B=32)."""
+    torch.set_num_threads(8)
+    net, d = ref_net(192, 192, 128, 1234)
+    x = torch.cat([rnd(600 + i, 1, 15, 128, 128) for i in range(9)], 0)
+    cond = torch.cat([rnd(700 + i, 1, 6, 128, 128) for i in range(9)], 0)
+    with torch.no_grad():
+        o = net(x, torch.tensor([500] * 9), cond=cond)
+        of = net(x[:2], torch.tensor([-0.5, -0.5]), cond=cond[:2])
+        od = net(x[:2], torch.tensor([99, 99]), cond=cond[:2])
+    save("forward_full_b9", samples=o.reshape(9, -1)[:, ::60].clone(),
+         stats=torch.stack([o.mean((1, 2, 3)), o.std((1, 2, 3)), o.abs().amax((1, 2, 3))], 1),
+         samples_tm05=of.reshape(2, -1)[:, ::60].clone(), samples_t99=od.reshape(2, -1)[:, ::60].clone())
+
+
+def gen_traj_full():
+    """Full-size 5-step DDPM trajectory (5 steps + denoise = 6 reference forwards), B=2, injected noise."""
+    from models import ddpm_sampler
+    torch.set_num_threads(8)
+    net, d = ref_net(192, 192, 128, 1234)
+    x_T, cond = rnd(801, 2, 15, 128, 128), rnd(802, 2, 6, 128, 128)
+    S = 5
+    noises = [rnd(810 + i, 2, 15, 128, 128) for i in range(S)]
+    it = iter(noises)
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **kw: next(it)
+    try:
+        out = ddpm_sampler(x_T.clone(), net, cond=cond, subsample_steps=S, denoise=True, clip_before=True,
+                           final_only=True, t_min=-1, log=True)
+    finally:
+        torch.randn_like = orig
+    o = out[0]
+    save("traj_full", samples=o.reshape(2, -1)[:, ::30].clone(), first_row=o[:, :, 0, :].clone(),
+         stats=torch.stack([o.mean(), o.std(), o.abs().max()]))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     gens = dict(schedule=gen_schedule, fir=gen_fir, blocks=gen_blocks, forward_reduced=gen_forward_reduced,
-                samplers=gen_samplers, forward_full=gen_forward_full)
+                samplers=gen_samplers, forward_full=gen_forward_full, forward_full_b9=gen_forward_full_b9,
+                traj_full=gen_traj_full)
     for name, fn in gens.items():
         if a.only and name != a.only:
             continue
-        if a.skip_full and name == "forward_full":
+        if a.skip_full and name in ("forward_full", "forward_full_b9", "traj_full"):
             continue
         fn()

@@ -65,3 +65,58 @@ def test_shard_plan_46_clips_over_8():
     assert [b - a for a, b in sizes] == [6, 6, 6, 6, 6, 6, 5, 5]
     assert sizes[0][0] == 0 and sizes[-1][1] == 46 and all(sizes[i][1] == sizes[i + 1][0] for i in range(7))
     assert shard_range(3, 5, 8) == (3, 3)   # more ranks than items: empty shard
+
+
+def _run_bench(args, env_extra, timeout=240):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_gpus2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` outside torchrun starts 2 ranks (child processes, gloo here) and relays rank 0's line:
+    n_gpus and ranks_seen are 2, never a silent 1-rank measurement."""
+    rc, line, err = _run_bench(["--gpus", "2", "--plumbing-only"], {"EVC_DIST_BACKEND": "gloo"})
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["self_launched"] is True
+    assert line["backend"] == "gloo" and line["broadcast_ok"] is True
+
+
+def test_bench_refuses_world_size_mismatch():
+    rc, line, err = _run_bench(["--gpus", "2", "--plumbing-only"], {"EVC_DIST_BACKEND": "gloo", "WORLD_SIZE": "1", "RANK": "0"})
+    assert rc == 2 and line is None and "WORLD_SIZE=1" in err
+
+
+def test_bench_parent_launches_before_any_gpu_call(monkeypatch):
+    """The self-launching parent must hand over to its children before it touches the GPU (a process that has
+    initialised HIP must not spawn-and-wait on this pool): with every torch.cuda entry point booby-trapped, main()
+    still reaches self_launch."""
+    import importlib.util
+    sys.path.insert(0, REPO)
+    import evc_amd  # noqa: F401
+    from evc_amd import dist as D
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+
+    def boom(*a, **k):
+        raise AssertionError("GPU touched before the ranks were launched")
+    for name in ("is_available", "set_device", "current_stream", "synchronize", "init", "device_count"):
+        monkeypatch.setattr(torch.cuda, name, boom)
+    monkeypatch.setattr(D, "self_launch", lambda script, argv, n, timeout=None: calls.append((script, list(argv), n)) or 0)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "1"])
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    assert calls and calls[0][2] == 4 and calls[0][1] == ["--gpus", "4", "--steps", "1"]

@@ -19,9 +19,15 @@ def L():
     return lib
 
 
-@pytest.fixture(params=[0, 1], ids=["f32mfma", "bf16x6"])
+@pytest.fixture(params=[0, 1, 2], ids=["f32mfma", "bf16x6", "f16x3"])
 def arith(request):
-    """Both multiplication schemes of the convolution (include/evc_hip.h EVC_ARITH_*), same tolerances."""
+    """All three multiplication schemes of the convolution (include/evc_hip.h EVC_ARITH_*), same tolerances (the
+    test inputs are O(1), which is what EVC_ARITH_F16X3 requires of its operands)."""
+    return request.param
+
+
+@pytest.fixture(params=[1, 2], ids=["bf16x6", "f16x3"])
+def split_arith(request):
     return request.param
 
 
@@ -122,7 +128,7 @@ def test_conv_fused_epilogue_moments_match_separate_pass(L, arith):
     (1, 4, 4, 16, 0, 192, 0),       # W = 4: 32 image rows per tile, M = 16 (mostly padding)
     (8, 128, 128, 16, 16, 64, 0),   # 512 tiles of 256 pixels: the 8-wave / 256-pixel form of the kernel
 ])
-def test_conv3x3_row_reuse_shapes(L, B, H, W, C0, C1, Co, splits):
+def test_conv3x3_row_reuse_shapes(L, split_arith, B, H, W, C0, C1, Co, splits):
     """3x3 convolutions on tiles made of whole image rows run on the row-reuse kernel (activation staged once per
     kernel row, taps read at shifted LDS offsets, zero halo pixels for the horizontal borders): every image width
     it supports, tiles spanning images, partial tiles, concat sources, GroupNorm+SiLU on load, split-K."""
@@ -134,21 +140,21 @@ def test_conv3x3_row_reuse_shapes(L, B, H, W, C0, C1, Co, splits):
     b, res = rnd(55, Co).cuda(), rnd(56, B, Co, H, W).cuda()
     xin = torch.cat([x0, x1], 1).cpu() if C1 else x0.cpu()
     ref = (F.conv2d(silu_affine(xin, a.cpu(), s.cpu()), w.cpu(), b.cpu(), padding=1) + res.cpu()) * 0.5
-    out = L.conv2d_nhwc(nhwc(x0), L.conv_pack_weights(w, L.ARITH_BF16X6), Co, 3, 3, bias=b,
+    out = L.conv2d_nhwc(nhwc(x0), L.conv_pack_weights(w, split_arith), Co, 3, 3, bias=b,
                         src1=None if x1 is None else nhwc(x1), coef=(a, s), act_in=L.ACT_SILU, res=nhwc(res),
                         out_scale=0.5, splits=splits)
     assert rel(nchw(out), ref) < 1e-5
     # plain (no transform) input through the same kernel
     ref2 = F.conv2d(xin, w.cpu(), None, padding=1)
-    out2 = L.conv2d_nhwc(nhwc(x0), L.conv_pack_weights(w, L.ARITH_BF16X6), Co, 3, 3,
+    out2 = L.conv2d_nhwc(nhwc(x0), L.conv_pack_weights(w, split_arith), Co, 3, 3,
                          src1=None if x1 is None else nhwc(x1), splits=splits)
     assert rel(nchw(out2), ref2) < 1e-5
 
 
 def test_conv_bf16x6_is_not_less_accurate_than_f32_mfma(L):
-    """The precision claim of EVC_ARITH_BF16X6, on the real kernel: against an fp64 reference its error is no larger
-    than that of the exact-product f32 MFMA path (both accumulate in fp32), for the dominant layer shape with
-    GroupNorm+SiLU on load and for a long-K split-K layer."""
+    """The precision claim of EVC_ARITH_BF16X6 and EVC_ARITH_F16X3, on the real kernels: against an fp64 reference
+    their error is no larger than that of the exact-product f32 MFMA path (all accumulate in fp32), for the dominant
+    layer shape with GroupNorm+SiLU on load and for a long-K split-K layer.  Same criterion for both."""
     for (B, H, W, Ci, Co, seed) in ((1, 32, 32, 192, 192, 40), (2, 8, 8, 1536, 768, 41)):
         x = rnd(seed, B, Ci, H, W).cuda()
         a, s = (1 + 0.2 * rnd(seed + 1, B, Ci)).cuda(), (0.3 * rnd(seed + 2, B, Ci)).cuda()
@@ -156,14 +162,36 @@ def test_conv_bf16x6_is_not_less_accurate_than_f32_mfma(L):
         xin = F.silu(x.double() * a.double()[:, :, None, None] + s.double()[:, :, None, None])
         ref = F.conv2d(xin, w.double(), None, padding=1)
         err = []
-        for ar in (L.ARITH_F32, L.ARITH_BF16X6):
+        for ar in (L.ARITH_F32, L.ARITH_BF16X6, L.ARITH_F16X3):
             out = L.conv2d_nhwc(nhwc(x), L.conv_pack_weights(w, ar), Co, 3, 3, coef=(a, s), act_in=L.ACT_SILU)
             e = (nchw(out).double() - ref).abs()
             err.append((float(e.max() / ref.abs().max()), float(e.pow(2).mean().sqrt() / ref.abs().max())))
-        (mx32, rms32), (mx6, rms6) = err
-        # the on-load SiLU uses the hardware exp/rcp (~1e-7 relative), common to both paths
-        assert mx32 < 5e-6 and mx6 < 5e-6, err
+        (mx32, rms32), (mx6, rms6), (mx3, rms3) = err
+        # the on-load SiLU uses the hardware exp/rcp (~1e-7 relative), common to all paths
+        assert mx32 < 5e-6 and mx6 < 5e-6 and mx3 < 5e-6, err
         assert rms6 <= 1.25 * rms32 and mx6 <= 2.0 * mx32, err
+        assert rms3 <= 1.25 * rms32 and mx3 <= 2.0 * mx32, err
+
+
+def test_conv_f16x3_scaling_and_saturation(L):
+    """EVC_ARITH_F16X3 range handling: the per-tensor weight scale makes tiny and huge weights equally accurate (the
+    inverse is applied to the accumulator), small activations keep their precision (absolute error of the split is
+    2^-25 / 8), and an activation beyond fp16's range saturates at 65504 / 8 instead of producing inf - inf = NaN."""
+    B, H, W, Ci, Co = 1, 16, 16, 64, 192
+    x = rnd(70, B, Ci, H, W).cuda()
+    w0 = rnd(71, Co, Ci, 3, 3) / np.sqrt(9 * Ci)
+    for wscale, xscale in ((1.0, 1.0), (1e-6, 1.0), (3e4, 1.0), (1.0, 0.01)):
+        w = (w0 * wscale).cuda()
+        ref = F.conv2d((x * xscale).double(), w.double(), None, padding=1)
+        out = L.conv2d_nhwc(nhwc(x * xscale), L.conv_pack_weights(w, L.ARITH_F16X3), Co, 3, 3)
+        assert float((nchw(out).double() - ref).abs().max() / ref.abs().max()) < 2e-6, (wscale, xscale)
+    xb = x.clone()
+    xb[0, 3, 5, 5] = 1e6                                    # far beyond 65504 / 8
+    out = L.conv2d_nhwc(nhwc(xb), L.conv_pack_weights(w0.cuda(), L.ARITH_F16X3), Co, 3, 3)
+    assert bool(torch.isfinite(out).all())
+    far = torch.ones(H, W, dtype=torch.bool); far[4:7, 4:7] = False     # pixels the outlier does not reach
+    ref = F.conv2d(x.cpu(), w0, None, padding=1)
+    assert rel(nchw(out)[0][:, far], ref[0][:, far]) < 1e-5
 
 
 def test_conv_rejects_bad_arguments(L):
@@ -173,6 +201,14 @@ def test_conv_rejects_bad_arguments(L):
         L.conv2d_nhwc(x, w, 64, 3, 3)
     with pytest.raises(L.EvcKernelError):
         L.conv_pack_weights(torch.zeros(64, 32, 3, 3, device="cuda"), arith=7)
+    with pytest.raises(ValueError):
+        import os
+        old = os.environ.get("EVC_CONV_ARITH")
+        os.environ["EVC_CONV_ARITH"] = "fp8"
+        try:
+            L.default_arith()
+        finally:
+            os.environ.pop("EVC_CONV_ARITH") if old is None else os.environ.__setitem__("EVC_CONV_ARITH", old)
 
 
 @pytest.mark.parametrize("B,H,W,C,G", [(2, 16, 16, 192, 32), (3, 8, 8, 1344, 32), (1, 32, 32, 32, 8), (2, 4, 4, 160, 32)])

@@ -48,9 +48,16 @@ def test_forward_ngf32_three_labels_incl_fractional_and_mixed_batch():
     assert rel(mixed[0], g["out_t0"][0]) < 1e-4 and rel(mixed[1], g["out_t990"][1]) < 1e-4
 
 
-def test_forward_full_size_against_reference_golden():
-    g = golden("forward_full")
+@pytest.fixture(scope="module")
+def full_net():
+    """The full-size (262 M parameter) network with the golden generator's seed, built once for the module."""
     net, d, p = build(192, 192, 128, 1234)
+    return net
+
+
+def test_forward_full_size_against_reference_golden(full_net):
+    g = golden("forward_full")
+    net = full_net
     x, cond = rnd(51, 1, 15, 128, 128).cuda(), rnd(52, 1, 6, 128, 128).cuda()
     o = net(x, torch.tensor([500]), cond=cond).cpu()
     assert rel(o.reshape(-1)[::60].numpy(), g["samples"]) < 2e-4
@@ -58,6 +65,55 @@ def test_forward_full_size_against_reference_golden():
     # batch invariance at full size: B=3 with identical samples gives identical outputs per sample
     o3 = net(x.repeat(3, 1, 1, 1), torch.tensor([500] * 3), cond=cond.repeat(3, 1, 1, 1)).cpu()
     assert rel(o3[2], o[0].numpy()) < 1e-5
+
+
+def _b9_inputs():
+    x = torch.cat([rnd(600 + i, 1, 15, 128, 128) for i in range(9)], 0).cuda()
+    cond = torch.cat([rnd(700 + i, 1, 6, 128, 128) for i in range(9)], 0).cuda()
+    return x, cond
+
+
+def test_forward_full_size_b9_one_launch_against_reference_golden(full_net):
+    """BASELINE configs[1]: the benchmark's own launch configuration -- nine different samples in ONE B=9 forward
+    (tile heights / split-K factors are chosen per batch size) -- against the reference run on the same batch."""
+    g = golden("forward_full_b9")
+    x, cond = _b9_inputs()
+    o = full_net(x, torch.tensor([500] * 9), cond=cond).cpu().reshape(9, -1)
+    for i in range(9):
+        assert rel(o[i, ::60].numpy(), g["samples"][i]) < 2e-4, i
+    st = g["stats"]
+    full = o.reshape(9, -1)
+    assert np.allclose(full.mean(1).numpy(), st[:, 0], atol=2e-4 * float(st[:, 2].max()))
+    assert np.allclose(full.std(1).numpy(), st[:, 1], rtol=2e-4)
+    # configs[4] (F-PNDM) feeds fractional / negative labels, DDPM's denoise call the count label 99: same B=9 launch
+    for key, lab in (("samples_tm05", -0.5), ("samples_t99", 99)):
+        o = full_net(x, torch.tensor([lab] * 9), cond=cond).cpu().reshape(9, -1)
+        for i in range(2):
+            assert rel(o[i, ::60].numpy(), g[key][i]) < 2e-4, (key, i)
+
+
+def test_forward_full_size_b32_cycled_against_reference_golden(full_net):
+    """BASELINE configs[4] batches 32 clips per launch: 256-pixel 8-wave tiles and other split choices than B=9.
+    32 inputs = the nine golden samples cycled; every output must match its sample's reference values."""
+    g = golden("forward_full_b9")
+    x, cond = _b9_inputs()
+    idx = torch.arange(32) % 9
+    o = full_net(x[idx.cuda()], torch.tensor([500] * 32), cond=cond[idx.cuda()]).cpu().reshape(32, -1)
+    for j in range(32):
+        assert rel(o[j, ::60].numpy(), g["samples"][j % 9]) < 2e-4, j
+
+
+def test_full_size_ddpm_trajectory_against_reference_golden(full_net):
+    """5 DDPM steps + the denoise call (6 full-size forwards, B=2, injected noise) against the reference sampler."""
+    import evc_amd  # noqa: F401
+    from evc_amd import sampler
+    g = golden("traj_full")
+    x_T, cond = rnd(801, 2, 15, 128, 128).cuda(), rnd(802, 2, 6, 128, 128).cuda()
+    noises = [rnd(810 + i, 2, 15, 128, 128) for i in range(5)]
+    out = sampler.ddpm_sampler(x_T, full_net, cond=cond, subsample_steps=5, denoise=True, clip_before=True,
+                               final_only=True, noise_fn=lambda i, x: noises[i])[0].cpu()
+    assert rel(out.reshape(2, -1)[:, ::30].numpy(), g["samples"]) < 5e-4
+    assert rel(out[:, :, 0, :].numpy(), g["first_row"]) < 5e-4
 
 
 def test_sampler_trajectories_against_reference_goldens():
