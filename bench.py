@@ -56,6 +56,11 @@ ARITH_INFO = {
 CONV_SOURCES = ("extreme-video-compression-with-prediction-using-pre-trainded-diffusion-models-_amd/csrc/conv_igemm.hip",)
 
 
+def progress(msg):
+    """Progress goes to stderr (stdout carries exactly one JSON line): long phases must not look like a hang."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,27 +207,32 @@ def cpu_baseline_leg(sd_d, sd_e, seconds):
     n_before = torch.get_num_threads()
     torch.set_num_threads(n_all)
 
-    def time_forwards(budget, max_n):
-        ON.forward(p, d, x, lab, cond=c)     # warm
+    def time_forwards(budget, max_n, warm=True):
+        if warm:
+            ON.forward(p, d, x, lab, cond=c)
         n, t0 = 0, time.time()
         while n < 1 or (time.time() - t0 < budget and n < max_n):
             ON.forward(p, d, x, lab, cond=c)
             n += 1
         return (time.time() - t0) / n, n
+    progress(f"cpu baseline: fp32 oracle forwards at {n_all} threads")
     t_all, n_fwd = time_forwards(seconds, 40)
+    progress(f"cpu baseline: {t_all:.2f} s/forward; 2-step DDPM chunk through the oracle sampler")
     # a 2-step DDPM chunk = 3 forwards + 2 updates + denoise: the per-step sampler cost beside the forwards
     t0 = time.time()
     OS.ddpm(x.clone(), lambda xx, t: ON.forward(p, d, xx, t, cond=c), OSch.base_schedule(), subsample_steps=2)
     t_chunk3 = time.time() - t0
     step_overhead = max(0.0, (t_chunk3 - 3 * t_all) / 3)
     chunk_all = 101 * (t_all + step_overhead)
+    progress("cpu baseline: one forward at 1 thread (the reference CLI's setting)")
     torch.set_num_threads(1)
     try:
-        t_one, n_one = time_forwards(min(seconds, 10.0), 2)
+        t_one, n_one = time_forwards(0.0, 1, warm=False)       # a single un-warmed forward: tens of seconds
     finally:
         torch.set_num_threads(n_all)
     # one ELIC key-frame decode on the CPU (oracle nets; range coding through the native coder, as compressai's is C++)
     elic_ms = None
+    progress(f"cpu baseline: {t_one:.1f} s/forward at 1 thread; one ELIC key-frame decode")
     try:
         from evc_amd import lib as L
 
@@ -301,6 +311,8 @@ def main():
     L.hip_lib()
     torch.cuda.set_device(device)
     cfg = default_config(192, 192, 128, subsample=a.subsample)
+    if rank == 0:
+        progress(f"rank 0 of {world}: building seeded weights, broadcast, packing")
 
     # weights: rank 0 owns the (synthetic, reference-layout) checkpoints; ONE broadcast per model over RCCL
     sd_d = synthetic.diffusion_state_dict(cfg, 1234) if rank == 0 else None
@@ -324,8 +336,11 @@ def main():
     def step():
         return dec.decode(d, key_strings, shape, generator=gen)
 
-    for _ in range(a.warmup):
+    for i in range(a.warmup):
         step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            progress(f"warm-up step {i + 1}/{a.warmup} done")
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -370,6 +385,7 @@ def main():
            "whole_path_tflops_per_gpu": round(flop_per_step_gpu * a.steps / elapsed / 1e12, 2),
            "elic_keyframe_decode_ms_per_step": round(elic_ms, 1)}
     if rank == 0:
+        progress(f"timed region: {elapsed:.2f} s for {a.steps} step(s) -> {value:.2f} frames/s; roofline + HBM probes")
         out["roofline"] = roofline_leg(net, a.clips, device)
         out["hbm_classes"] = hbm_classes_leg(a.clips, device)
         out["cpu_baseline"] = None if a.no_cpu_baseline else cpu_baseline_leg(sd_d, sd_e, a.cpu_baseline_seconds)

@@ -4,11 +4,12 @@
     python city_sender.py --data_npy data_npy/city_bonn.npy --output_path out/ --start_idx 0 --end_idx 8
 
 Differences, all additive: ``--q`` selects ELIC quality indexes (the reference hard-codes 4 and 5,
-city_sender.py:504), ``--sampler DDPM|DDIM|FPNDM``, ``--policy mask|psnr`` (+ ``--thresholds``): the
-reference decides with LPIPS (city_sender.py:376-406), whose AlexNet backbone cannot be fetched offline, so the
-policy loop is restated with the reference's own PSNR rule (``decide_5to5``, city_sender.py:353-374) or a fixed
-transmit mask; ``--synthetic`` builds seeded stand-ins when checkpoints / data are absent.  Under
-``torch.distributed.run`` the video range is block-sharded over ranks (one GPU each).
+city_sender.py:504), ``--sampler DDPM|DDIM|FPNDM``, ``--policy mask|psnr|lpips`` (+ ``--thresholds``, ``--metric``):
+``lpips`` is the reference's rule (``decide_5to5_lpips``, city_sender.py:376-406, thresholds 0.30 ... 0.03) and needs a
+perceptual metric -- the ``lpips`` package with torchvision's pretrained AlexNet, or ``--metric pkg.module:callable``;
+neither can be fetched offline, so ``psnr`` (the reference's own ``decide_5to5``, city_sender.py:353-374) is the
+tested rule and ``mask`` a fixed transmit mask; ``--synthetic`` builds seeded stand-ins when checkpoints / data are
+absent.  ``--gpus N`` (or ``torch.distributed.run``) block-shards the video range over N ranks, one GPU each.
 """
 import argparse
 import os
@@ -46,9 +47,19 @@ def build_parser():
     # --- additions ---
     p.add_argument("--q", type=int, nargs="+", default=[4, 5], help="ELIC quality indexes (reference loop: 4 5)")
     p.add_argument("--sampler", default="DDPM", choices=["DDPM", "DDIM", "FPNDM"])
-    p.add_argument("--policy", default="mask", choices=["mask", "psnr"])
+    p.add_argument("--policy", default="mask", choices=["mask", "psnr", "lpips"])
     p.add_argument("--thresholds", type=float, nargs="+", default=None,
-                   help="psnr policy: dB thresholds (reference sweeps LPIPS 0.30..0.03, city_sender.py:508)")
+                   help="psnr policy: dB thresholds; lpips policy: distances (default: the reference's sweep "
+                        "0.30, 0.29 ... 0.03, city_sender.py:508)")
+    p.add_argument("--metric", type=str, default=None,
+                   help="lpips policy: package.module:callable, fn(pred, gt) -> distances for (n,3,H,W) tensors in [0,1]")
+    p.add_argument("--policy-batch", type=int, default=32,
+                   help="psnr / lpips policy: (video, q, threshold) jobs stacked per score-network launch")
+    p.add_argument("--bpp-limit", type=float, default=1.0,
+                   help="psnr / lpips policy: a (video, q) sweep stops at the first threshold whose rate reaches this "
+                        "many bits per pixel (city_sender.py:563-564)")
+    p.add_argument("--gpus", type=int, default=1,
+                   help="ranks (one per GPU) to shard the video range over; > 1 outside torchrun starts them itself")
     p.add_argument("--synthetic", action="store_true", help="seeded stand-ins for missing checkpoints / data")
     p.add_argument("--batch", type=int, default=8,
                    help="mask policy: clips decoded together per GPU (the reference runs one clip at a time)")
@@ -81,7 +92,11 @@ def save_output(gt, xge, q, thr, idx, output_dir):
 def main(argv=None):
     args = build_parser().parse_args(argv)
     import yaml
-    from . import ckpt, config as C, dist as D, lib as L, sampler as S, synthetic
+    from . import dist as D
+    if D.needs_self_launch(args.gpus):      # parent: starts the ranks before any HIP call, relays their exit status
+        script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "city_sender.py")
+        sys.exit(D.self_launch(script, sys.argv[1:] if argv is None else list(argv), args.gpus))
+    from . import ckpt, config as C, lib as L, sampler as S, synthetic
     from .decoder import ClipDecoder
     from .elic import ElicModel, inference
     from .scorenet import ScoreNet
@@ -91,6 +106,8 @@ def main(argv=None):
         cfg.sampling.subsample = args.subsample
     cfg.sampling.ckpt_id = args.ckpt or cfg.sampling.ckpt_id
     rank, world, device = D.init()
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     L.hip_lib()
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
@@ -133,7 +150,10 @@ def main(argv=None):
 
     lo, hi = D.shard_range(args.end_idx + 1 - args.start_idx, rank, world)
     gen = torch.Generator(device=device).manual_seed(args.seed + rank)
-    thresholds = args.thresholds if args.policy == "psnr" and args.thresholds else [0.0]
+    if args.policy == "lpips":       # city_sender.py:508: np.arange(0.30, 0.02, -0.01) rounded to 2 decimals
+        thresholds = args.thresholds or [float("%.2f" % t) for t in np.arange(0.30, 0.02, -0.01)]
+    else:
+        thresholds = args.thresholds if args.policy == "psnr" and args.thresholds else [0.0]
     t_start = time.time()
     vids = list(range(args.start_idx + lo, args.start_idx + hi))
 
@@ -173,65 +193,44 @@ def main(argv=None):
                     os.makedirs(args.bitstream_dir, exist_ok=True)
                     path = os.path.join(args.bitstream_dir, f"clips_{chunk[0]}_{chunk[-1]}_q{q}.evc")
                     with open(path, "wb") as fh:
-                        fh.write(container.pack(mask, keys, shape))
-                    with open(path, "rb") as fh:
-                        d_rx, keys_rx, shape_rx = container.unpack(fh.read())
+                        fh.write(container.pack(mask, keys, shape, codec=model.codec_tag()))
+                    with open(path, "rb") as fh:          # refuses a stream coded under another arithmetic
+                        d_rx, keys_rx, shape_rx = container.unpack(fh.read(), expect_codec=model.codec_tag())
                 frames = dec.decode(d_rx, keys_rx, shape_rx, generator=gen)[..., :gt.shape[-2], :gt.shape[-1]]
                 x_all = frames.cpu().numpy()
                 for j, vid in enumerate(chunk):
                     bits = [count_bits([[[[p[j]] for p in sl] for sl in k[0]], [k[1][j]]]) for k in keys]
                     report(vid, q, 0.0, x_all[j], gt[j].numpy(), bits, mask, store)
     else:
-        # PSNR policy (city_sender.py:534-548, decide_5to5 :353-374).  The reference runs the whole clip once per
-        # threshold; here all thresholds of a (clip, q) advance together: every round, the jobs that need a
-        # generation are stacked along the batch axis of ONE score-network launch, and key
-        # frames are coded once per frame index and shared by every threshold that falls back to them.
+        # city_sender.py:495-607 batched (policy.py): every (video, q, threshold) job of this rank advances in lockstep,
+        # `--policy-batch` jobs per score-network launch; key frames coded once per (video, q, frame).
+        from . import policy as P
+        metric = P.load_metric(args.policy, args.metric, device)
+        dec = ClipDecoder(net, None, cfg, S.get_sampler(args.sampler))
+        clips = {vid: torch.from_numpy(np.asarray(data[vid], dtype=np.float32) / 255.0) for vid in vids}
+        res = P.run_policy(dec, models, clips, args.q, thresholds, metric, patch=args.patch, max_batch=args.policy_batch,
+                           seed=args.seed, device=device, bpp_limit=args.bpp_limit, log=lambda m: print(f"[rank {rank}] {m}", flush=True))
+        metric_vals = {}
         for vid in vids:
-            gt = torch.from_numpy(np.asarray(data[vid], dtype=np.float32) / 255.0)          # (30,3,H,W)
             for q in args.q:
-                model = models[q]
-                dec = ClipDecoder(net, model, cfg, S.get_sampler(args.sampler))
-                key_cache = {}
-
-                def key_frame(f):
-                    if f not in key_cache:
-                        xh, b = inference(model, gt[f].to(device), args.patch)
-                        key_cache[f] = (xh[0], b)
-                    return key_cache[f]
-
-                jobs = []
-                for thr in thresholds:
-                    j = dict(thr=thr, x=[], bits=[], d=[])
-                    for f in (0, 1):                                     # key frames (city_sender.py:521-524)
-                        xh, b = key_frame(f)
-                        j["x"].append(xh); j["bits"].append(b); j["d"].append(1)
-                    jobs.append(j)
-                while True:
-                    active = [j for j in jobs if len(j["x"]) < 30]
-                    if not active:
-                        break
-                    cond = torch.stack([torch.stack(j["x"][-2:], 0) for j in active], 0)     # (n_active, 2, 3, H, W)
-                    pred = dec.generate(cond.contiguous(), generator=gen)                   # (n_active, 5, 3, H, W)
-                    pred_np = pred.cpu().numpy()
-                    for k, j in enumerate(active):
-                        l = len(j["x"])
-                        acc = 0
-                        for t in range(min(5, 30 - l)):
-                            if cal_psnr(pred_np[k, t], gt[l + t].numpy()) < j["thr"]:
-                                break
-                            j["x"].append(pred[k, t]); j["d"].append(0); acc += 1
-                        if acc == 0:
-                            for f in (l, l + 1):
-                                if f < 30:
-                                    xh, b = key_frame(f)
-                                    j["x"].append(xh); j["bits"].append(b); j["d"].append(1)
-                for j in jobs:
-                    x = torch.stack(j["x"][:30], 0).cpu().numpy()
-                    report(vid, q, j["thr"], x, gt.numpy(), j["bits"], j["d"], store)
+                for r in res[(vid, q)]:
+                    report(vid, q, r["thr"], r["x"], clips[vid].numpy(), r["bits"], r["d"], store)
+                    if args.policy == "lpips":      # per-frame distances of the decoded clip (city_sender.py:570-571)
+                        v = metric.values(torch.from_numpy(r["x"]).to(device), clips[vid].to(device))
+                        metric_vals.setdefault(vid, []).append(v)
+        for vid, vals in metric_vals.items():
+            out_root = os.path.join(args.output_path, f"output_{vid}")
+            np.save(os.path.join(out_root, f"lpips_frames_{vid}.npy"), np.asarray(vals))
+            np.save(os.path.join(out_root, f"lpips_{vid}.npy"),
+                    P.rd_envelope(store[vid][1], np.mean(np.asarray(vals), 1), higher_is_better=False))
     for vid, (ps, bpps) in store.items():
         out_root = os.path.join(args.output_path, f"output_{vid}")
         os.makedirs(out_root, exist_ok=True)
-        np.save(os.path.join(out_root, f"psnr_{vid}.npy"), np.asarray(ps))
+        # reference names (function.py:148-230): psnr_<idx>.npy = RD envelope [bpp; mean PSNR] of the video's sweep;
+        # the raw sweep is kept beside it (per-threshold per-frame PSNR, per-threshold bpp)
+        from .policy import rd_envelope
+        np.save(os.path.join(out_root, f"psnr_{vid}.npy"), rd_envelope(bpps, np.mean(np.asarray(ps), 1), True))
+        np.save(os.path.join(out_root, f"psnr_frames_{vid}.npy"), np.asarray(ps))
         np.save(os.path.join(out_root, f"bpp_{vid}.npy"), np.asarray(bpps))
     D.barrier()
     if rank == 0:

@@ -25,6 +25,9 @@ from .entropy import EntropyBottleneckCodec, Tables
 
 GROUPS = [0, 16, 16, 32, 64, 192]   # Network.py:87
 ONE = np.ones((1, 1), dtype=np.float32)
+# Bumped whenever a change to the convolution kernels can alter the last bit of the entropy-parameter networks' outputs
+# (summation order, tile shapes ...): streams carry it (container.py) and receivers refuse a mismatch.
+ELIC_CODEC_REV = 2
 
 
 def _pad16(c):
@@ -36,6 +39,7 @@ class ElicModel:
         L.hip_lib()
         self.device = torch.device(device)
         self.N, self.M = N, M
+        self.arith = L.default_arith()          # operand ranges are unknown here: never the fp16 split
         sd = state_dict
         self.w = {}
         for k in sd:
@@ -61,12 +65,16 @@ class ElicModel:
                 wp = torch.zeros(co, cip, kh, kw)
                 wp[:, :ci] = w
                 w = wp
-            self.w[name] = dict(w=L.conv_pack_weights(w.to(self.device)), b=sd[name + ".bias"].detach().float().to(self.device),
+            self.w[name] = dict(w=L.conv_pack_weights(w.to(self.device), self.arith), b=sd[name + ".bias"].detach().float().to(self.device),
                                 co=co, k=kh)
         self.gc = Tables.from_state_dict(sd, "gaussian_conditional")
         self.scale_table = sd["gaussian_conditional.scale_table"].detach().float().to(self.device).contiguous()
         self.eb = EntropyBottleneckCodec(Tables.from_state_dict(sd, "entropy_bottleneck"),
                                          sd["entropy_bottleneck.quantiles"][:, 0, 1].detach().float().cpu().numpy())
+
+    def codec_tag(self):
+        """(convolution arithmetic, kernel revision) the entropy parameters of this model are computed with."""
+        return (self.arith, ELIC_CODEC_REV)
 
     @staticmethod
     def _is_deconv(name):

@@ -24,8 +24,10 @@ def test_cli_end_to_end_synthetic(tmp_path, monkeypatch):
     for v in (1, 2):     # three clips in batches of 2 + 1
         assert os.path.exists(out / f"output_{v}" / f"city_output_npy_idx{v}_q3_thr0.00.npy")
     bpp = np.load(d / "bpp_0.npy")
-    psnr = np.load(d / "psnr_0.npy")
+    psnr = np.load(d / "psnr_frames_0.npy")
     assert bpp.shape == (1,) and 0 < bpp[0] and psnr.shape == (1, 30)
+    env = np.load(d / "psnr_0.npy")           # reference file name: RD envelope [bpp; mean PSNR] (function.py:148-230)
+    assert env.shape == (2, 1) and env[0, 0] == bpp[0] and abs(env[1, 0] - psnr.mean()) < 1e-9
     assert os.path.exists(tmp_path / "exp" / "video_samples" / "arg_config" / "config.yml")
     # the receiver decoded from the container file: its payload is exactly the bits the sender reported
     from evc_amd import container
@@ -37,8 +39,53 @@ def test_cli_end_to_end_synthetic(tmp_path, monkeypatch):
     # PSNR policy: an unreachable threshold rejects every generated frame -> everything is key-coded (more bits);
     # a trivially low one accepts everything -> same mask as above
     base[base.index("--end_idx") + 1] = "0"
-    cli.main(base + ["--policy", "psnr", "--thresholds", "200", "-100"])
+    cli.main(base + ["--policy", "psnr", "--thresholds", "200", "-100", "--bpp-limit", "1e9"])
     bpp2 = np.load(d / "bpp_0.npy")
     assert bpp2.shape == (2,) and bpp2[0] > 5 * bpp2[1] and abs(bpp2[1] - bpp[0]) / bpp[0] < 0.2
-    psnr2 = np.load(d / "psnr_0.npy")
+    psnr2 = np.load(d / "psnr_frames_0.npy")
     assert psnr2.shape == (2, 30)
+    assert np.load(d / "psnr_0.npy").shape[0] == 2
+
+
+def test_batched_policy_sweep_equals_one_job_at_a_time():
+    """policy.run_policy advances every (video, q, threshold) job in lockstep, stacked along the batch axis; with
+    per-job noise streams the accept / fall-back decisions (the transmit masks d) and the bit counts equal those of a
+    sweep that runs one job per launch -- the reference's order (city_sender.py:504-550)."""
+    import torch
+    import evc_amd  # noqa: F401
+    from evc_amd import policy as P, sampler as S, synthetic
+    from evc_amd.config import default_config
+    from evc_amd.decoder import ClipDecoder
+    from evc_amd.elic import ElicModel
+    from evc_amd.scorenet import ScoreNet
+    from oracle import scorenet as ON
+    cfg = default_config(32, 32, 128, subsample=2)
+    net = ScoreNet(cfg, ON.seeded_params(ON.Dims(ngf=32, n_head_channels=32, image_size=128), 3))
+    models = {3: ElicModel(synthetic.elic_state_dict(3)), 4: ElicModel(synthetic.elic_state_dict(4))}
+    dec = ClipDecoder(net, None, cfg, S.get_sampler("DDPM"))
+    clips = {v: torch.from_numpy(synthetic.make_clips(v + 1, seed=11)[v].astype(np.float32) / 255) for v in (0, 1)}
+    # thresholds around the PSNR a random-weight generator reaches (~5-12 dB): some accept, some fall back
+    probe = P.run_policy(dec, models, {0: clips[0]}, [3], [-100.0], P.PsnrMetric(), seed=5)
+    mid = float(np.median([P.cal_psnr(probe[(0, 3)][0]["x"][t], clips[0][t].numpy()) for t in range(2, 30)]))
+    thr = [mid + 1.0, mid, mid - 1.0, -100.0, 200.0]
+    many = P.run_policy(dec, models, clips, [3, 4], thr, P.PsnrMetric(), max_batch=7, seed=5, bpp_limit=1e9)
+    one = P.run_policy(dec, models, clips, [3, 4], thr, P.PsnrMetric(), max_batch=1, seed=5, bpp_limit=1e9)
+    cut = P.run_policy(dec, models, {0: clips[0]}, [3], [200.0, -100.0], P.PsnrMetric(), seed=5, bpp_limit=1e-9)
+    assert cut[(0, 3)] == []                                    # `if NN_bpp >= limit: break` ends the (video, q) sweep
+    assert set(many) == set(one) == {(0, 3), (0, 4), (1, 3), (1, 4)}
+    n_mixed = 0
+    for k in many:
+        assert [r["thr"] for r in many[k]] == [r["thr"] for r in one[k]]
+        for a, b in zip(many[k], one[k]):
+            assert (a["d"] == b["d"]).all() and a["bits"] == b["bits"], (k, a["thr"])
+            assert float(np.abs(a["x"] - b["x"]).max()) < 2e-3
+            n_mixed += 0 < a["d"][2:].sum() < 28
+        lo = [r for r in many[k] if r["thr"] == -100.0][0]
+        assert lo["d"].sum() == 2                               # accepts everything: only the two initial key frames
+        hi = [r for r in many[k] if r["thr"] == 200.0]
+        assert hi[0]["d"].sum() == 30                           # rejects everything: all 30 frames key-coded
+    assert n_mixed > 0                                          # the sweep exercised partial acceptance
+    # RD envelope of the sweep: part of the points, sorted along the hull
+    env = P.rd_envelope([r["bpp"] for r in many[(0, 3)]], [np.mean([P.cal_psnr(r["x"][t], clips[0][t].numpy())
+                                                                     for t in range(30)]) for r in many[(0, 3)]], True)
+    assert env.shape[0] == 2 and 1 <= env.shape[1] <= len(many[(0, 3)])

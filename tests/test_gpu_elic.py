@@ -82,3 +82,45 @@ def test_inference_wrapper_pad_crop_and_bits(setup):
     assert x_hat.shape == (1, 3, 100, 120) and bits > 0 and bits % 32 == 0
     enc = model.compress(torch.nn.functional.pad(img[None], (0, 8, 0, 28)))
     assert bits == count_bits(enc["strings"])
+
+
+def test_receiver_refuses_stream_coded_under_another_arithmetic(setup, monkeypatch):
+    """The container records the arithmetic the encoder's entropy-parameter networks ran with; a receiver built under
+    EVC_CONV_ARITH=f32 refuses a bf16x6 stream (CodecMismatch) instead of desynchronising its range decoder."""
+    import evc_amd  # noqa: F401
+    from evc_amd import container, lib
+    from evc_amd.elic import ElicModel
+    sd, model, x = setup
+    assert model.codec_tag()[0] == lib.ARITH_BF16X6      # the fp16 split is never used for ELIC (unbounded operands)
+    enc = model.compress(x[:2])
+    d = np.zeros(30, dtype=np.int64)
+    d[0] = 1
+    blob = container.pack(d, [enc["strings"]], enc["shape"], codec=model.codec_tag())
+    monkeypatch.setenv("EVC_CONV_ARITH", "f32")
+    rx = ElicModel(sd)
+    assert rx.codec_tag()[0] == lib.ARITH_F32
+    with pytest.raises(container.CodecMismatch):
+        container.unpack(blob, expect_codec=rx.codec_tag())
+    d2, keys, shape = container.unpack(blob, expect_codec=model.codec_tag())      # the matching receiver decodes
+    out = model.decompress(keys[0], shape)["x_hat"]
+    assert torch.equal(out, model.decompress(enc["strings"], enc["shape"])["x_hat"])
+
+
+@pytest.mark.parametrize("name,Ci,Co,K", [("h_s.4", 320, 640, 3), ("cc_transforms", 224, 128, 5), ("ParamAggregation", 1024, 640, 1)])
+def test_entropy_parameter_convs_are_bitwise_batch_invariant(name, Ci, Co, K):
+    """Encoder and decoder may run the entropy-parameter convolutions at different batch sizes (the receiver decodes
+    key-frame runs at 2B): tile height, row-reuse kernel and 256-pixel tiles are chosen from the grid size, so the
+    per-sample outputs must be BITWISE equal across every such switch, for both arithmetics ELIC can run with."""
+    import evc_amd  # noqa: F401
+    from evc_amd import lib as L
+    w = (rnd(300, Co, Ci, K, K) / np.sqrt(Ci * K * K)).cuda()
+    b = rnd(301, Co).cuda()
+    for arith in (L.ARITH_BF16X6, L.ARITH_F32):
+        wp = L.conv_pack_weights(w, arith)
+        for (H, W) in ((8, 8), (32, 32)):
+            x1 = rnd(302, 1, H, W, Ci).cuda()
+            ref = L.conv2d_nhwc(x1, wp, Co, K, K, bias=b, act_out=L.ACT_RELU, splits=1)
+            for B in (2, 3, 9, 18, 64):       # 8x8: M = 128 .. 4096 pixels; 32x32: 2048 .. 65536 (256-pixel tiles)
+                xb = torch.cat([rnd(310 + i, 1, H, W, Ci) for i in range(B - 1)] + [x1.cpu()], 0).cuda()
+                out = L.conv2d_nhwc(xb, wp, Co, K, K, bias=b, act_out=L.ACT_RELU, splits=1)
+                assert torch.equal(out[-1], ref[0]), (name, arith, H, B)

@@ -106,7 +106,43 @@ def test_container_roundtrip_and_corruption():
     blob = container.pack(d, keys, (2, 2))
     d2, keys2, shape = container.unpack(blob)
     assert shape == (2, 2) and (d2 == d).all() and keys2 == keys
-    assert container.payload_bits(keys2) == 8 * (len(blob) - 14 - 30 - 4 * 3 * B * 11)
-    for bad in (blob[:-3], b"XXXX" + blob[4:], blob + b"\0"):
+    assert container.payload_bits(keys2) == 8 * (len(blob) - container.HEADER_BYTES - 30 - 4 * 3 * B * 11)
+    for bad in (blob[:-3], b"XXXX" + blob[4:], blob + b"\0", blob[:4] + b"\x07" + blob[5:]):
         with pytest.raises(ValueError):
             container.unpack(bad)
+    # codec tag: the encoder's arithmetic / kernel revision travels with the stream and a mismatch is refused
+    assert container.read_codec(blob) == (1, 1)
+    blob6 = container.pack(d, keys, (2, 2), codec=(1, 2))
+    assert container.unpack(blob6, expect_codec=(1, 2))[2] == (2, 2)
+    for other in ((0, 2), (1, 3)):          # f32 receiver of a bf16x6 stream; same arithmetic, other kernel revision
+        with pytest.raises(container.CodecMismatch):
+            container.unpack(blob6, expect_codec=other)
+
+
+def test_policy_metrics_hook_and_rd_envelope():
+    """Host logic of the sender policy (evc_amd/policy.py): the PSNR rule (decide_5to5), the pluggable LPIPS-style hook
+    (decide_5to5_lpips needs a backbone that cannot be fetched offline), and the RD-envelope selection."""
+    import torch
+    from evc_amd import policy as P
+    a, b = torch.rand(3, 3, 8, 8), torch.rand(3, 3, 8, 8)
+    v = P.PsnrMetric().values(a, b)
+    ref = [10 * np.log10(1.0 / np.mean((a[i].double().numpy() - b[i].double().numpy()) ** 2)) for i in range(3)]
+    assert np.allclose(v, ref) and P.PsnrMetric.accept(30.0, 30.0) and not P.PsnrMetric.accept(29.9, 30.0)
+    # the hook: "module:callable" returning one distance per frame, accepted while distance <= threshold
+    m = P.load_metric("lpips", "torch.nn.functional:l1_loss")
+    assert isinstance(m, P.CallableMetric) and m.accept(0.1, 0.1) and not m.accept(0.11, 0.1)
+    m2 = P.CallableMetric(lambda p, g: (p - g).abs().mean((1, 2, 3)))
+    assert np.allclose(m2.values(a, b), (a - b).abs().mean((1, 2, 3)).numpy())
+    with pytest.raises(RuntimeError, match="lpips"):
+        P.load_metric("lpips", None)          # no backbone offline: a clear error, never a silent PSNR substitute
+    with pytest.raises(ValueError):
+        P.load_metric("ssim")
+    # RD envelope: concave (PSNR, higher better) / convex (LPIPS, lower better) boundary of the sweep's points
+    bpp = np.array([0.05, 0.1, 0.2, 0.4, 0.8, 0.3])
+    psnr = np.array([20.0, 26.0, 30.0, 32.0, 33.0, 25.0])           # the last point lies under the hull
+    env = P.rd_envelope(bpp, psnr, True)
+    assert env.shape[0] == 2 and 25.0 not in env[1] and 33.0 in env[1] and set(env[0]) <= set(bpp)
+    lp = np.array([0.30, 0.22, 0.15, 0.11, 0.10, 0.28])
+    env2 = P.rd_envelope(bpp, lp, False)
+    assert env2.shape[0] == 2 and 0.28 not in env2[1] and 0.10 in env2[1]
+    assert P.rd_envelope([0.1], [30.0], True).shape == (2, 1)       # a fixed-mask run has a single point

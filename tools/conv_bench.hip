@@ -16,6 +16,7 @@ int main(int argc, char** argv) {
     const int layout = argc > 1 ? atoi(argv[1]) : 0;
     const int iters = argc > 2 ? atoi(argv[2]) : 10;
     const int only = argc > 3 ? atoi(argv[3]) : -1;
+    const bool skip_f32 = layout == 5;         // layout 5: split arithmetics only (faster A/B)
     (void)layout;
     std::vector<Shape> shapes = {{8, 128, 192, 192, 3, 0}, {8, 128, 192, 192, 3, 1}, {9, 128, 192, 192, 3, 1},
                                  {8, 128, 384, 192, 3, 1}, {8, 64, 384, 384, 3, 0}, {8, 64, 384, 384, 3, 1},
@@ -81,8 +82,8 @@ int main(int argc, char** argv) {
         const Shape& s = shapes[si];
         const size_t nx = (size_t)s.B * s.R * s.R * s.Ci, no = (size_t)s.B * s.R * s.R * s.Co;
         const size_t nraw = (size_t)s.Co * s.Ci * s.K * s.K;
-        float *x, *wraw, *o[2], *ca, *cs, *ws;
-        void* wp[2];
+        float *x, *wraw, *o[3], *ca, *cs, *ws;
+        void* wp[3];
         CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&wraw, nraw * 4));
         CK(hipMalloc(&ca, (size_t)s.B * s.Ci * 4)); CK(hipMalloc(&cs, (size_t)s.B * s.Ci * 4));
         std::vector<float> h(std::max(nx, nraw));
@@ -93,9 +94,10 @@ int main(int argc, char** argv) {
         std::vector<float> one((size_t)s.B * s.Ci, 1.0f), zero((size_t)s.B * s.Ci, 0.1f);
         CK(hipMemcpy(ca, one.data(), one.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(cs, zero.data(), zero.size() * 4, hipMemcpyHostToDevice));
-        double tf[2] = {0, 0};
+        double tf[3] = {0, 0, 0};
         int nsplit = 0;
-        for (int arith = 0; arith < 2; ++arith) {
+        for (int arith = 0; arith < 3; ++arith) {
+            if (arith == 0 && skip_f32) { o[0] = nullptr; wp[0] = nullptr; continue; }
             CK(hipMalloc(&o[arith], no * 4));
             CK(hipMalloc(&wp[arith], (size_t)evc_conv_packed_bytes(s.Co, s.Ci, s.K, s.K, arith)));
             if (evc_conv_pack_weights(wraw, wp[arith], s.Co, s.Ci, s.K, s.K, arith, nullptr) != 0) { printf("pack failed\n"); return 1; }
@@ -120,15 +122,16 @@ int main(int argc, char** argv) {
             nsplit = evc_conv_choose_splits(&a);
             if (ws) hipFree(ws);
         }
-        std::vector<float> r0(no), r1(no);
-        CK(hipMemcpy(r0.data(), o[0], no * 4, hipMemcpyDeviceToHost));
+        std::vector<float> r1(no), r2(no);
         CK(hipMemcpy(r1.data(), o[1], no * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(r2.data(), o[2], no * 4, hipMemcpyDeviceToHost));
         double mx = 0, sc = 0;
-        for (size_t i = 0; i < no; ++i) { mx = std::max(mx, (double)std::fabs(r0[i] - r1[i])); sc = std::max(sc, (double)std::fabs(r0[i])); }
-        printf("B=%d %3dx%-3d %4d->%-4d k%d %s splits=%d : f32 %.1f TF/s   bf16x6 %.1f TF/s   max|diff|/max|out| %.2e\n", s.B, s.R, s.R,
-               s.Ci, s.Co, s.K, s.mode ? "gn+silu" : "plain  ", nsplit, tf[0], tf[1], mx / sc);
-        hipFree(wraw); hipFree(o[0]); hipFree(o[1]); hipFree(wp[0]); hipFree(wp[1]); float* w = nullptr; float* o_ = nullptr; (void)o_;
-        hipFree(x); hipFree(ca); hipFree(cs); (void)w;
+        for (size_t i = 0; i < no; ++i) { mx = std::max(mx, (double)std::fabs(r1[i] - r2[i])); sc = std::max(sc, (double)std::fabs(r1[i])); }
+        printf("B=%d %3dx%-3d %4d->%-4d k%d %s splits=%d : f32 %.1f   bf16x6 %.1f   f16x3 %.1f TF/s   max|f16x3-bf16x6|/max|out| %.2e\n", s.B, s.R, s.R,
+               s.Ci, s.Co, s.K, s.mode ? "gn+silu" : "plain  ", nsplit, tf[0], tf[1], tf[2], mx / sc);
+        fflush(stdout);
+        hipFree(wraw); for (int q = 0; q < 3; ++q) { if (o[q]) hipFree(o[q]); if (wp[q]) hipFree(wp[q]); }
+        hipFree(x); hipFree(ca); hipFree(cs);
     }
     return 0;
 }
