@@ -202,9 +202,11 @@ def cpu_baseline_leg(sd_d, sd_e, seconds):
     p = {k: v.cpu() for k, v in sd_d.items() if k.startswith("unet.all_modules.")}
     x, c = torch.randn(1, 15, 128, 128), torch.randn(1, 6, 128, 128)
     lab = torch.tensor([500])
-    # torchrun exports OMP_NUM_THREADS=1 to its ranks: "all threads" means the cores this process may run on
-    n_all = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # "all threads" = torch's own default (one per physical core).  torchrun exports OMP_NUM_THREADS=1 to its ranks:
+    # then fall back to the physical core count.  Never the logical-CPU count: 256 threads on this box's CPU share
+    # oversubscribe it and run 50x slower (measured: 135 s per forward instead of ~2.5 s).
     n_before = torch.get_num_threads()
+    n_all = n_before if n_before > 1 else min(physical or os.cpu_count() or 1, 128)
     torch.set_num_threads(n_all)
 
     def time_forwards(budget, max_n, warm=True):

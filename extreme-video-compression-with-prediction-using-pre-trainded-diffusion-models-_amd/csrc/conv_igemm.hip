@@ -59,6 +59,19 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #ifndef EVC_RR_OCC
 #define EVC_RR_OCC 2           // workgroups per CU the 4-wave row-reuse kernel is register-budgeted for
 #endif
+#ifndef EVC_RR_BALANCE
+#define EVC_RR_BALANCE 0       // row-reuse kernel: 1 = the staging arithmetic of the next activation image is spread over two
+                               // K-steps (transform during tx = 1, split + LDS write during tx = 2); 0 = all of it in tx = 2.
+#endif
+#ifndef EVC_RR_INTERLEAVE
+#define EVC_RR_INTERLEAVE 0    // row-reuse kernel: VALU instructions scheduled behind each MFMA in the staging blocks (0 = the
+                               // compiler's order: the whole staging block between two groups of MFMAs).
+#endif
+// Both measured on MI355X for f16x3 (profiles/r02_conv_bench_rr_staging_ab.log, two interleaved rounds per build):
+// balance / interleave 2 / interleave 3 are within +-2 % of the plain order on every layer shape (128x128 192->192 B=9:
+// 307 / 303 / 298 / 303 TFLOP/s) -- where the staging VALU work sits inside a macro-step does not matter, the partner
+// wave's MFMAs cover it either way; EVC_RR_OCC = 3 spills (188 -> 168 VGPRs) and loses 20-25 % on GroupNorm+SiLU
+// layers, gains 5 % on plain ones.  Kept as switches, off.
 // (Round-1 variants that measured no gain -- producer/consumer specialised kernels, row reuse on the f32 MFMA -- live in
 //  tools/experiments/conv_variants_r01.hip.inc, outside the product translation unit.)
 
@@ -1076,9 +1089,14 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
         if (w_tx == 3) { w_tx = 0; ++w_ty; }
         if (w_ty == 3) { w_ty = 0; w_off += w_wrap; }
     };
+    float4 treg[2];                                  // transformed activations between tx = 1 and tx = 2 (EVC_RR_BALANCE)
+    auto transform_a = [&]() {
+        treg[0] = transform<MODE>(areg[0], ca[0], cs[0], aok);
+        treg[1] = transform<MODE>(areg[1], ca[1], cs[1], aok);
+    };
     auto store_a = [&](int ab) {
         vec pl[NP];
-        SP::split(transform<MODE>(areg[0], ca[0], cs[0], aok), transform<MODE>(areg[1], ca[1], cs[1], aok), pl);
+        SP::split(treg[0], treg[1], pl);
         char* A = As + ab * NP * APL + a_lds;
 #pragma unroll
         for (int q = 0; q < NP; ++q) *reinterpret_cast<vec*>(A + q * APL) = pl[q];
@@ -1101,6 +1119,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
         load_coefs();
         load_a();
         dma_w(0);
+        transform_a();
         store_a(0);
         if (1 < nst) advance_w();
     }
@@ -1142,24 +1161,56 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
             __builtin_amdgcn_sched_barrier(0);
             wb ^= 1; ++sidx;
         }
+        // MFMAs of one K-step with the staging VALU work `WORK` spread behind them (EVC_RR_INTERLEAVE per MFMA)
+#define EVC_RR_STEP_WITH(TX, WORK)                                                                      \
+        {                                                                                               \
+            EVC_RR_FRAGS(TX)                                                                            \
+            if (EVC_RR_INTERLEAVE) {                                                                    \
+                WORK;                                                                                   \
+                EVC_RR_TERMS(0, SP::NTERM)                                                              \
+                __builtin_amdgcn_sched_group_barrier(0x100, NP * (TM + TN), 0);      /* fragment reads */  \
+                _Pragma("unroll") for (int q_ = 0; q_ < SP::NTERM * TM * TN; ++q_) {                    \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
+                    __builtin_amdgcn_sched_group_barrier(0x002, EVC_RR_INTERLEAVE, 0);                  \
+                }                                                                                       \
+            } else {                                                                                    \
+                EVC_RR_TERMS(0, SP::NTERM / 2)                                                          \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+                WORK;                                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+                EVC_RR_TERMS(SP::NTERM / 2, SP::NTERM)                                                  \
+            }                                                                                           \
+        }
         {   // ---- tx = 1 ----
+#if EVC_RR_BALANCE
+            // the activation registers of the next macro-step (loaded during tx = 0) must have landed BEFORE this step's
+            // weight DMA is queued behind them: vmcnt counts in order, a later wait for them would drain the DMA too
+            __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0), expcnt / lgkmcnt untouched
+            EVC_RR_NEXT_W()
+            __builtin_amdgcn_sched_barrier(0);
+            EVC_RR_STEP_WITH(1, transform_a())
+            __builtin_amdgcn_sched_barrier(0);
+#else
             EVC_RR_NEXT_W()
             EVC_RR_FRAGS(1)
             EVC_RR_TERMS(0, SP::NTERM)
+#endif
             __syncthreads();
             wb ^= 1; ++sidx;
         }
         {   // ---- tx = 2: stage the next macro-step's activation image among the MFMAs ----
             EVC_RR_NEXT_W()
-            EVC_RR_FRAGS(2)
-            EVC_RR_TERMS(0, SP::NTERM / 2)
             __builtin_amdgcn_sched_barrier(0);
-            store_a(ab ^ 1);
+#if EVC_RR_BALANCE
+            EVC_RR_STEP_WITH(2, store_a(ab ^ 1))
+#else
+            EVC_RR_STEP_WITH(2, (transform_a(), store_a(ab ^ 1)))
+#endif
             __builtin_amdgcn_sched_barrier(0);
-            EVC_RR_TERMS(SP::NTERM / 2, SP::NTERM)
             __syncthreads();
             wb ^= 1; ++sidx;
         }
+#undef EVC_RR_STEP_WITH
     }
 #undef EVC_RR_TERMS
 #undef EVC_RR_FRAGS
