@@ -96,7 +96,19 @@ struct ConvK {
     float* ws;   // split-K slabs [splits][M][Co] when splits > 1
     float* stats;   // optional fused per-channel moments [M/64][Co][2]
     const float* w_hdr;   // f16x3 only: header of the packed weights, [0] = 1 / (activation scale * weight scale)
+    const unsigned* in_bound;   // f16x3 only, optional: bit pattern of a float B with |src element| <= sqrt(B) (see in_scale)
 };
+
+// f16x3 on a source with no GroupNorm in front of it (raw residual stream, attention output): the caller supplies a bound
+// on the tensor's elements, taken from its per-channel moments (evc_gn_coeffs_bound_f32 / evc_moments_bound_f32), and the
+// whole tensor is scaled by the power of two that brings that bound into [2^6, 2^7) before the fp16 split: nothing can
+// overflow (<= 2^7 * 8 = 1024), typical elements sit far above fp16's subnormals, and the exact inverse goes into the
+// accumulator scale.  Wave-uniform, evaluated once per kernel.
+__device__ __forceinline__ float in_scale(const ConvK& p) {
+    if (!p.in_bound) return 1.0f;
+    const float b = sqrtf(__uint_as_float(*p.in_bound));
+    return (b > 0.f && b < 3.0e38f) ? ldexpf(1.0f, 6 - ilogbf(b)) : 1.0f;
+}
 
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
@@ -141,7 +153,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
     constexpr int BN = 64 * TN;
     const bool partial = p.splits > 1;
     // f16x3: the operands were scaled by powers of two to sit in fp16's range; undo it here (exact)
-    const float ascale = p.w_hdr ? p.w_hdr[0] : 1.0f;
+    const float ascale = p.w_hdr ? p.w_hdr[0] / in_scale(p) : 1.0f;
     const int mw = m0 + wm * 32 * TM + 4 * half;
     const int cw = n0 + wn * 32 * TN + l31;
     if (m0 + BM <= p.M && n0 + BN <= p.Co) {
@@ -448,11 +460,11 @@ __device__ __forceinline__ void split3_bf16(const float4& v0, const float4& v1, 
 // evc_amd/scorenet.py).
 constexpr float F16_ACT_SCALE = 8.0f;
 
-__device__ __forceinline__ void split2_f16(const float4& v0, const float4& v1, f16x8& p1, f16x8& p2) {
+__device__ __forceinline__ void split2_f16(const float4& v0, const float4& v1, float xscale, f16x8& p1, f16x8& p2) {
     const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float v = __builtin_amdgcn_fmed3f(x[j] * F16_ACT_SCALE, -65504.0f, 65504.0f);
+        const float v = __builtin_amdgcn_fmed3f(x[j] * xscale, -65504.0f, 65504.0f);
         const _Float16 a = (_Float16)v;
         p1[j] = a; p2[j] = (_Float16)(v - (float)a);
     }
@@ -469,7 +481,7 @@ template <> struct Split<3> {
     static __device__ __forceinline__ f32x16 mfma(const vec& a, const vec& b, const f32x16& c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
-    static __device__ __forceinline__ void split(const float4& v0, const float4& v1, vec (&pl)[3]) {
+    static __device__ __forceinline__ void split(const float4& v0, const float4& v1, float, vec (&pl)[3]) {
         split3_bf16(v0, v1, pl[0], pl[1], pl[2]);
     }
 };
@@ -481,8 +493,8 @@ template <> struct Split<2> {
     static __device__ __forceinline__ f32x16 mfma(const vec& a, const vec& b, const f32x16& c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
-    static __device__ __forceinline__ void split(const float4& v0, const float4& v1, vec (&pl)[2]) {
-        split2_f16(v0, v1, pl[0], pl[1]);
+    static __device__ __forceinline__ void split(const float4& v0, const float4& v1, float xscale, vec (&pl)[2]) {
+        split2_f16(v0, v1, xscale, pl[0], pl[1]);
     }
 };
 
@@ -578,6 +590,7 @@ __global__ __launch_bounds__(256, 2) void conv_splitn_kernel(ConvK p) {
     };
     float4 areg[2] = {}, ca[2], cs[2];
     bool aok = false;
+    const float xscale = F16_ACT_SCALE * in_scale(p);      // used by the fp16 split only
     auto load_coefs = [&]() {
         if (HAS_COEF) {
             const size_t co = (size_t)rb * Ct + c_chunk * KC + 8 * kh;
@@ -609,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void conv_splitn_kernel(ConvK p) {
     auto store_a = [&](int buf) {
         if (!a_active || (EVC_CONV_ABLATE & 2)) return;
         vec pl[NP];
-        SP::split(transform<MODE>(areg[0], ca[0], cs[0], aok), transform<MODE>(areg[1], ca[1], cs[1], aok), pl);
+        SP::split(transform<MODE>(areg[0], ca[0], cs[0], aok), transform<MODE>(areg[1], ca[1], cs[1], aok), xscale, pl);
         char* A = As + buf * NP * BM * RB + a_lds;
 #pragma unroll
         for (int q = 0; q < NP; ++q) *reinterpret_cast<vec*>(A + q * BM * RB) = pl[q];
@@ -1089,6 +1102,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
         if (w_tx == 3) { w_tx = 0; ++w_ty; }
         if (w_ty == 3) { w_ty = 0; w_off += w_wrap; }
     };
+    const float xscale = F16_ACT_SCALE * in_scale(p);     // used by the fp16 split only
     float4 treg[2];                                  // transformed activations between tx = 1 and tx = 2 (EVC_RR_BALANCE)
     auto transform_a = [&]() {
         treg[0] = transform<MODE>(areg[0], ca[0], cs[0], aok);
@@ -1096,7 +1110,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
     };
     auto store_a = [&](int ab) {
         vec pl[NP];
-        SP::split(treg[0], treg[1], pl);
+        SP::split(treg[0], treg[1], xscale, pl);
         char* A = As + ab * NP * APL + a_lds;
 #pragma unroll
         for (int q = 0; q < NP; ++q) *reinterpret_cast<vec*>(A + q * APL) = pl[q];
@@ -1650,6 +1664,11 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     k.coef_a = a->coef_a; k.coef_s = a->coef_s;
     k.w = a->w_packed; k.bias = a->bias; k.res = a->res; k.ld_res = a->ld_res;
     k.w_hdr = nullptr;
+    k.in_bound = nullptr;
+    if (a->in_bound) {
+        if (a->arith != EVC_ARITH_F16X3) return EVC_EINVAL;        // only the fp16 split scales its input
+        k.in_bound = a->in_bound;
+    }
     if (a->arith == EVC_ARITH_F16X3) {     // [header][planes]
         k.w_hdr = a->w_packed;
         k.w = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a->w_packed) + F16_HDR_BYTES);

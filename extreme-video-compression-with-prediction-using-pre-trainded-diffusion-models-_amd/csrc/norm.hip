@@ -66,6 +66,7 @@ struct CoefArgs {
     int B, HW, groups; float eps; int mode;
     const float* gamma; const float* beta; const float* ss; int ss_ld; const int* row;
     float* coef_a; float* coef_s;
+    unsigned* bound_bits;      // optional: atomicMax of the bit pattern of the largest {sum of squares} entry seen
 };
 
 // grid (groups, B), block 256: the (split, channel) moments of one group are summed in double by the whole
@@ -77,27 +78,31 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(CoefArgs a) {
     const int cpg = C / a.groups;
     const int c_begin = g * cpg;
     double sm = 0.0, sq = 0.0;
+    float mx = 0.f;            // largest sum-of-squares entry: sqrt(mx) bounds every element of the tensor(s)
     // channels of this group that live in source 0 / source 1
     const int n0 = max(0, min(c_begin + cpg, a.C0) - c_begin);
     const int n1 = cpg - n0;
     for (int i = tid; i < n0 * a.nsplit0; i += 256) {
         const int s = i / n0, cc = c_begin + (i - s * n0);
         const float2 e = *reinterpret_cast<const float2*>(a.part0 + ((size_t)(b * a.nsplit0 + s) * a.C0 + cc) * 2);
-        sm += (double)e.x; sq += (double)e.y;
+        sm += (double)e.x; sq += (double)e.y; mx = fmaxf(mx, e.y);
     }
     if (n1 > 0) {
         const int c1 = c_begin + n0 - a.C0;
         for (int i = tid; i < n1 * a.nsplit1; i += 256) {
             const int s = i / n1, cc = c1 + (i - s * n1);
             const float2 e = *reinterpret_cast<const float2*>(a.part1 + ((size_t)(b * a.nsplit1 + s) * a.C1 + cc) * 2);
-            sm += (double)e.x; sq += (double)e.y;
+            sm += (double)e.x; sq += (double)e.y; mx = fmaxf(mx, e.y);
         }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         sm += __shfl_xor(sm, off);
         sq += __shfl_xor(sq, off);
+        mx = fmaxf(mx, __shfl_xor(mx, off));
     }
+    // max is order-independent, so the atomic keeps the result deterministic; non-negative floats order like their bits
+    if (a.bound_bits && (tid & 63) == 0 && mx > 0.f) atomicMax(a.bound_bits, __float_as_uint(mx));
     if ((tid & 63) == 0) { red[0][tid >> 6] = sm; red[1][tid >> 6] = sq; }
     __syncthreads();
     sm = red[0][0] + red[0][1] + red[0][2] + red[0][3];
@@ -120,6 +125,18 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(CoefArgs a) {
         a.coef_a[(size_t)b * C + c] = ca;
         a.coef_s[(size_t)b * C + c] = add - fmean * ca;
     }
+}
+
+// max over a channel range of a moments tensor [B][nsplit][C][2]: the bound of a tensor that has no GroupNorm in
+// front of it (evc_moments_bound_f32).  grid (nsplit, B).
+__global__ __launch_bounds__(256) void moments_bound_kernel(const float* __restrict__ part, int nsplit, int C, int c_begin,
+                                                            int c_count, unsigned* __restrict__ bound_bits) {
+    const float* row = part + ((size_t)(blockIdx.y * nsplit + blockIdx.x) * C + c_begin) * 2;
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < c_count; i += 256) mx = fmaxf(mx, row[2 * i + 1]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(bound_bits, __float_as_uint(mx));
 }
 
 __device__ __forceinline__ float act_fn(float v, int act) {
@@ -160,16 +177,38 @@ extern "C" int evc_chan_stats_f32(const float* x, float* partial, int B, int HW,
     return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
 }
 
+extern "C" int evc_gn_coeffs_bound_f32(const float* part0, int nsplit0, int C0, const float* part1, int nsplit1, int C1,
+                                       int B, int HW, int groups, float eps, int mode, const float* gamma,
+                                       const float* beta, const float* ss, int ss_ld, const int* row, float* coef_a,
+                                       float* coef_s, unsigned* bound_bits, void* stream);
+
 extern "C" int evc_gn_coeffs_f32(const float* part0, int nsplit0, int C0, const float* part1, int nsplit1, int C1,
                                  int B, int HW, int groups, float eps, int mode, const float* gamma,
                                  const float* beta, const float* ss, int ss_ld, const int* row, float* coef_a,
                                  float* coef_s, void* stream) {
+    return evc_gn_coeffs_bound_f32(part0, nsplit0, C0, part1, nsplit1, C1, B, HW, groups, eps, mode, gamma, beta, ss,
+                                   ss_ld, row, coef_a, coef_s, nullptr, stream);
+}
+
+extern "C" int evc_moments_bound_f32(const float* part, int nsplit, int C, int c_begin, int c_count, int B,
+                                     unsigned* bound_bits, void* stream) {
+    if (!part || !bound_bits || nsplit <= 0 || C <= 0 || B <= 0 || c_begin < 0 || c_count <= 0 || c_begin + c_count > C)
+        return EVC_EINVAL;
+    hipLaunchKernelGGL(moments_bound_kernel, dim3(nsplit, B), dim3(256), 0, (hipStream_t)stream, part, nsplit, C,
+                       c_begin, c_count, bound_bits);
+    return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
+}
+
+extern "C" int evc_gn_coeffs_bound_f32(const float* part0, int nsplit0, int C0, const float* part1, int nsplit1, int C1,
+                                       int B, int HW, int groups, float eps, int mode, const float* gamma,
+                                       const float* beta, const float* ss, int ss_ld, const int* row, float* coef_a,
+                                       float* coef_s, unsigned* bound_bits, void* stream) {
     if (!part0 || C0 <= 0 || nsplit0 <= 0 || C1 < 0 || (C1 > 0 && (!part1 || nsplit1 <= 0))) return EVC_EINVAL;
     if (B <= 0 || HW <= 0 || groups <= 0 || (C0 + C1) % groups != 0 || !coef_a || !coef_s) return EVC_EINVAL;
     if (mode < 0 || mode > 2 || (mode == 1 && (!gamma || !beta)) || (mode == 2 && (!ss || ss_ld < 2 * (C0 + C1))))
         return EVC_EINVAL;
     CoefArgs a{part0, nsplit0, C0, part1, nsplit1, C1, B, HW, groups, eps, mode, gamma, beta, ss, ss_ld, row,
-               coef_a, coef_s};
+               coef_a, coef_s, bound_bits};
     hipLaunchKernelGGL(gn_coeffs_kernel, dim3(groups, B), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
 }

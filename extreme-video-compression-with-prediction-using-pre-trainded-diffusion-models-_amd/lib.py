@@ -64,7 +64,7 @@ class ConvArgs(ctypes.Structure):
                 ("out_scale", c_float), ("act_out", c_int),
                 ("out", c_void_p), ("ld_out", c_int),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("Co", c_int), ("KH", c_int), ("KW", c_int),
-                ("splits", c_int), ("stats_out", c_void_p), ("arith", c_int)]
+                ("splits", c_int), ("stats_out", c_void_p), ("arith", c_int), ("in_bound", c_void_p)]
 
 
 # name -> (restype, argtypes); exactly the symbols declared in include/evc_hip.h
@@ -82,6 +82,10 @@ HIP_SYMBOLS = {
     "evc_gn_coeffs_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                   c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
+    "evc_gn_coeffs_bound_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                        c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p]),
+    "evc_moments_bound_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "evc_affine_act_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_void_p]),
     "evc_conv_co_pad": (c_int, [c_int]),
@@ -262,8 +266,10 @@ def chan_stats(x):
     return part
 
 
-def gn_coeffs(parts, HW, groups, eps, mode=0, gamma=None, beta=None, ss=None, row=None):
-    """parts: one or two partial-moment tensors (virtual concat). Returns (coef_a, coef_s), each (B, C)."""
+def gn_coeffs(parts, HW, groups, eps, mode=0, gamma=None, beta=None, ss=None, row=None, bound=None):
+    """parts: one or two partial-moment tensors (virtual concat). Returns (coef_a, coef_s), each (B, C).
+    ``bound``: optional one-element int32 tensor (zeroed by the caller) raised to the bit pattern of the tensors'
+    element bound S (|x| <= sqrt(S)) -- what ``conv2d_nhwc(..., in_bound=)`` takes."""
     L = hip_lib()
     p0 = parts[0]
     p1 = parts[1] if len(parts) > 1 else None
@@ -273,10 +279,26 @@ def gn_coeffs(parts, HW, groups, eps, mode=0, gamma=None, beta=None, ss=None, ro
     ca = torch.empty((B, C), device=p0.device, dtype=torch.float32)
     cs = torch.empty((B, C), device=p0.device, dtype=torch.float32)
     ss_ld = 0 if ss is None else ss.stride(0)
-    _check(L.evc_gn_coeffs_f32(fptr(p0), ns0, C0, fptr(p1), ns1, C1, B, HW, groups, eps, mode, fptr(gamma),
-                               fptr(beta), c_void_p(ss.data_ptr()) if ss is not None else None, ss_ld,
-                               fptr(row, torch.int32), fptr(ca), fptr(cs), stream_ptr()), "evc_gn_coeffs_f32")
+    _check(L.evc_gn_coeffs_bound_f32(fptr(p0), ns0, C0, fptr(p1), ns1, C1, B, HW, groups, eps, mode, fptr(gamma),
+                                     fptr(beta), c_void_p(ss.data_ptr()) if ss is not None else None, ss_ld,
+                                     fptr(row, torch.int32), fptr(ca), fptr(cs), _word(bound), stream_ptr()),
+           "evc_gn_coeffs_bound_f32")
     return ca, cs
+
+
+def _word(t):
+    """Device pointer of a one-element int32 tensor (or view), None when absent."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.int32 and t.numel() == 1
+    return c_void_p(t.data_ptr())
+
+
+def moments_bound(part, c_begin, c_count, bound):
+    """Raise ``bound`` to the element bound of channels [c_begin, c_begin + c_count) of a moments tensor (B, ns, C, 2)."""
+    B, ns, C, _ = part.shape
+    _check(hip_lib().evc_moments_bound_f32(fptr(part), ns, C, c_begin, c_count, B, _word(bound), stream_ptr()),
+           "evc_moments_bound_f32")
 
 
 def affine_act(x, coef, act, out=None, coef_col=0):
@@ -366,7 +388,7 @@ def _src(s):
 
 
 def conv2d_nhwc(src0, w_packed, Co, KH, KW, bias=None, src1=None, coef=None, act_in=ACT_NONE, res=None,
-                out_scale=1.0, act_out=ACT_NONE, out=None, splits=0, want_stats=False):
+                out_scale=1.0, act_out=ACT_NONE, out=None, splits=0, want_stats=False, in_bound=None):
     """out = act_out((conv(act_in(cat[src0,src1]*a+s), w) + bias + res) * out_scale); tensors are NHWC.
     ``src0`` / ``src1`` / ``out`` may be ``Cols`` channel slices of wider tensors.
     ``want_stats=True`` returns ``(out, stats)``: per-channel moments of ``out`` in ``chan_stats`` layout, produced
@@ -384,7 +406,7 @@ def conv2d_nhwc(src0, w_packed, Co, KH, KW, bias=None, src1=None, coef=None, act
     ca, cs = coef if coef is not None else (None, None)
     a = ConvArgs(p0, p1, C0, C1, ld0, ld1, ptr(ca), ptr(cs), act_in, ptr(w_packed), ptr(bias), ptr(res),
                  0 if res is None else res.shape[-1], float(out_scale), act_out, po, ldo,
-                 B, H, W, Co, KH, KW, splits, None, packed_arith(w_packed))
+                 B, H, W, Co, KH, KW, splits, None, packed_arith(w_packed), _word(in_bound))
     stats = None
     if want_stats:
         ns = L.evc_conv_stats_splits(ctypes.byref(a))
@@ -416,7 +438,7 @@ def conv_fused_stats_splits(B, H, W, Ci, Co, KH, KW, splits=0, arith=None):
     combine for this shape, 0 when it falls back to a separate ``evc_chan_stats_f32`` pass (C query, no launch)."""
     d = c_void_p(16)   # any non-null pointers: the query validates shapes only
     a = ConvArgs(d, None, Ci, 0, 0, 0, None, None, ACT_NONE, d, None, None, 0, 1.0, ACT_NONE, d, Co, B, H, W, Co, KH,
-                 KW, splits, None, default_arith() if arith is None else arith)
+                 KW, splits, None, default_arith() if arith is None else arith, None)
     return hip_lib(require_device=False).evc_conv_stats_splits(ctypes.byref(a))
 
 

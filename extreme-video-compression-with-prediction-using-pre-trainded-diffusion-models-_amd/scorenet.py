@@ -143,6 +143,11 @@ class ScoreNet:
         # so it is off by default; useful when the host thread has other work.
         self.use_graphs = use_graphs
         self._graphs = {}
+        # fp16-split convolutions on raw (un-normalised) inputs take an element bound from the tensors' moments
+        self._f16_raw = L.bounded_arith() == L.ARITH_F16X3
+        self._bounds_by_stream = {}      # concurrent clip groups run forwards on their own streams: one arena each
+        self._bounds = None
+        self._bound_next = 0
 
     # ------------------------------------------------------------------------------------------
     def _dev(self, t):
@@ -186,7 +191,9 @@ class ScoreNet:
                 e["w0"] = self._pack_conv(g(n + ".Conv_0.weight"), bounded=True); e["b0"] = self._dev(g(n + ".Conv_0.bias"))
                 e["w1"] = self._pack_conv(g(n + ".Conv_1.weight"), bounded=True); e["b1"] = self._dev(g(n + ".Conv_1.bias"))
                 if m["cin"] != m["cout"] or m["up"] or m["down"]:
-                    e["w2"] = self._pack_conv(g(n + ".Conv_2.weight")); e["b2"] = self._dev(g(n + ".Conv_2.bias"))
+                    # 1x1 skip convolution on the raw residual stream: fp16 split too, scaled by the element bound that
+                    # the block's own GroupNorm moments give (gn_coeffs(..., bound=))
+                    e["w2"] = self._pack_conv(g(n + ".Conv_2.weight"), bounded=True); e["b2"] = self._dev(g(n + ".Conv_2.bias"))
                 self.w[i] = e
             elif k == "attn":
                 ws = [g(f"{n}.NIN_{j}.W") for j in range(4)]   # (in, out): conv weight is the transpose
@@ -196,7 +203,8 @@ class ScoreNet:
                                  beta=self._dev(g(n + ".GroupNorm_0.bias")),
                                  wqkv=self._pack_conv(wqkv, bounded=True),     # input: affine GroupNorm
                                  bqkv=self._dev(torch.cat(bs[:3], 0)),
-                                 wo=self._pack_conv(ws[3].t()[:, :, None, None]), bo=self._dev(bs[3]))
+                                 # output projection: |attention output| <= max |v|, bounded through v's moments
+                                 wo=self._pack_conv(ws[3].t()[:, :, None, None], bounded=True), bo=self._dev(bs[3]))
             elif k == "norm":
                 self.w[i] = dict(gamma=self._dev(g(n + ".Norm_0.weight")), beta=self._dev(g(n + ".Norm_0.bias")))
         self.ss_total = off
@@ -245,17 +253,27 @@ class ScoreNet:
         return t
 
     # ------------------------------------------------------------------------------------------
-    def _adagn(self, parts, hw, ch, seg, rows):
+    def _adagn(self, parts, hw, ch, seg, rows, bound=None):
         off, c = seg
         assert c == ch
-        return L.gn_coeffs(parts, hw, num_groups(ch), 1e-5, mode=2, ss=self._table[:, off:off + 2 * c], row=rows)
+        return L.gn_coeffs(parts, hw, num_groups(ch), 1e-5, mode=2, ss=self._table[:, off:off + 2 * c], row=rows,
+                           bound=bound)
+
+    def _bound_slot(self):
+        """A zeroed device word of this forward's arena (element bounds for fp16-split convolutions on raw inputs)."""
+        if not self._f16_raw:
+            return None
+        w = self._bounds[self._bound_next:self._bound_next + 1]
+        self._bound_next += 1
+        return w
 
     def _res(self, i, m, x, skip, rows):
         """ResnetBlockBigGANppGN.forward (models/better/layerspp.py:595-624)."""
         e = self.w[i]
         B, H, W, _ = x.t.shape
         parts = [x.stats()] + ([skip.stats()] if skip is not None else [])
-        coef0 = self._adagn(parts, H * W, m["cin"], e["ss0"], rows)
+        xbound = self._bound_slot() if "w2" in e else None     # bounds x (and skip): also FIR(x), whose taps sum to 1
+        coef0 = self._adagn(parts, H * W, m["cin"], e["ss0"], rows, bound=xbound)
         if m["up"] or m["down"]:
             if m["up"]:
                 k, up, down, pad = FIR_K * 4.0, 2, 1, (2, 1)     # upsample_2d: gain factor**2, pad (2, 1)
@@ -282,7 +300,7 @@ class ScoreNet:
         H1, W1 = h1.t.shape[1], h1.t.shape[2]
         coef1 = self._adagn([h1.stats()], H1 * W1, m["cout"], e["ss1"], rows)
         if "w2" in e:
-            xs = L.conv2d_nhwc(xs_src, e["w2"], m["cout"], 1, 1, bias=e["b2"], src1=xs_skip)
+            xs = L.conv2d_nhwc(xs_src, e["w2"], m["cout"], 1, 1, bias=e["b2"], src1=xs_skip, in_bound=xbound)
         else:
             xs = xs_src
         if self.preactivate:
@@ -299,10 +317,15 @@ class ScoreNet:
         hd = self.d.n_head_channels
         heads = 1 if C < hd else C // hd
         coef = L.gn_coeffs([x.stats()], H * W, num_groups(C), 1e-6, mode=1, gamma=e["gamma"], beta=e["beta"])
-        qkv = L.conv2d_nhwc(x.t, e["wqkv"], 3 * C, 1, 1, bias=e["bqkv"], coef=coef)
+        obound = self._bound_slot()
+        if obound is None:
+            qkv = L.conv2d_nhwc(x.t, e["wqkv"], 3 * C, 1, 1, bias=e["bqkv"], coef=coef)
+        else:       # the attention output is a convex combination of value rows: max |o| <= max |v| <= sqrt(bound of v)
+            qkv, qst = L.conv2d_nhwc(x.t, e["wqkv"], 3 * C, 1, 1, bias=e["bqkv"], coef=coef, want_stats=True)
+            L.moments_bound(qst, 2 * C, C, obound)
         o = L.attention(qkv.view(B, H * W, 3 * C), C, heads)
         return _Act(*L.conv2d_nhwc(o.view(B, H, W, C), e["wo"], C, 1, 1, bias=e["bo"], res=x.t,
-                                   out_scale=INV_SQRT2, want_stats=True))
+                                   out_scale=INV_SQRT2, want_stats=True, in_bound=obound))
 
     @torch.no_grad()
     def forward_rows(self, x, rows, cond=None):
@@ -310,6 +333,13 @@ class ScoreNet:
         d = self.d
         prog = self.program
         B, _, H, W = x.shape
+        if self._f16_raw:
+            key = torch.cuda.current_stream().cuda_stream
+            self._bounds = self._bounds_by_stream.get(key)
+            if self._bounds is None:
+                self._bounds = self._bounds_by_stream[key] = torch.zeros(128, device=self.device, dtype=torch.int32)
+            self._bounds.zero_()          # one memset per forward; slots are handed out in program order
+            self._bound_next = 0
         i = 2
         m = prog[i]
         xin = L.pack_nchw_to_nhwc(x, cond, self.w[i]["cin_pad"])

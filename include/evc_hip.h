@@ -87,6 +87,18 @@ int evc_gn_coeffs_f32(const float* part0, int nsplit0, int C0, const float* part
                       int HW, int groups, float eps, int mode, const float* gamma, const float* beta,
                       const float* ss, int ss_ld, const int* row, float* coef_a, float* coef_s, void* stream);
 
+/* evc_gn_coeffs_f32 that additionally raises *bound_bits (atomic max; the caller zeroes it first) to the bit pattern of
+ * the largest {sum of squares} entry among the moments it read: sqrt of that float bounds every element of the tensor(s),
+ * because each element belongs to exactly one entry.  Deterministic (max is order-independent).  bound_bits may be NULL. */
+int evc_gn_coeffs_bound_f32(const float* part0, int nsplit0, int C0, const float* part1, int nsplit1, int C1, int B,
+                            int HW, int groups, float eps, int mode, const float* gamma, const float* beta,
+                            const float* ss, int ss_ld, const int* row, float* coef_a, float* coef_s,
+                            unsigned* bound_bits, void* stream);
+/* The same bound over channels [c_begin, c_begin + c_count) of one moments tensor [B][nsplit][C][2] (for tensors that are
+ * not followed by a GroupNorm, e.g. the value projection feeding attention). */
+int evc_moments_bound_f32(const float* part, int nsplit, int C, int c_begin, int c_count, int B, unsigned* bound_bits,
+                          void* stream);
+
 /* y = act(x*coef_a[b][c] + coef_s[b][c]) elementwise on NHWC: the stand-alone form of the fused load.  One pass per
  * tensor instead of once per filter tap inside the convolution (SiLU costs MFMA issue slots there; HBM is cheap).
  * `coef_*` rows have stride ld_coef (0 = C) so a slice of a concat's coefficients can be used; `y` rows have stride
@@ -123,6 +135,12 @@ typedef struct {
                               evc_chan_stats_f32 with nsplit = evc_conv_stats_splits() ([B][nsplit][Co][2] = {sum, sumsq}
                               of each pixel run). Only honoured when that is > 0; else must be NULL. */
     int arith;             /* EVC_ARITH_*: must match the packing of w_packed */
+    const unsigned* in_bound;  /* EVC_ARITH_F16X3 only, optional (NULL otherwise): device word holding the bit pattern of a
+                              float S such that every element of src0 / src1 satisfies |x| <= sqrt(S) -- written by
+                              evc_gn_coeffs_bound_f32 / evc_moments_bound_f32 from the tensors' moments.  The kernel scales
+                              the sources by the power of two that brings sqrt(S) into [64, 128) before the fp16 split and
+                              the accumulator by its inverse: lets the fp16 arithmetic take inputs that no GroupNorm has
+                              normalised (1x1 skip convolutions, NIN output projections). */
 } evc_conv_args;
 int evc_conv_co_pad(int Co);
 long long evc_conv_packed_floats(int Co, int Ci, int KH, int KW);

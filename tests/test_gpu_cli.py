@@ -78,13 +78,39 @@ def test_batched_policy_sweep_equals_one_job_at_a_time():
         assert [r["thr"] for r in many[k]] == [r["thr"] for r in one[k]]
         for a, b in zip(many[k], one[k]):
             assert (a["d"] == b["d"]).all() and a["bits"] == b["bits"], (k, a["thr"])
-            assert float(np.abs(a["x"] - b["x"]).max()) < 2e-3
+            # frames: the first chunk agrees to fp32 sampler tolerance; later chunks chain on it and a random-weight
+            # generator amplifies the ~1e-6 differences between launch configurations (tile / split-K choices depend on
+            # the batch size) by ~100x per chunk (tools/dbg_batch.py), so only the decisions above are compared there
+            assert float(np.abs(a["x"][:7] - b["x"][:7]).max()) < 2e-3
             n_mixed += 0 < a["d"][2:].sum() < 28
         lo = [r for r in many[k] if r["thr"] == -100.0][0]
         assert lo["d"].sum() == 2                               # accepts everything: only the two initial key frames
         hi = [r for r in many[k] if r["thr"] == 200.0]
         assert hi[0]["d"].sum() == 30                           # rejects everything: all 30 frames key-coded
-    assert n_mixed > 0                                          # the sweep exercised partial acceptance
+    # partial acceptance by construction: an LPIPS-style metric (accept while distance <= threshold) that depends on the
+    # ground-truth frame only, i.e. on the frame index -- every job sees accepted prefixes, rejections and fall-backs
+    def fake_distance(pred, gt):
+        return torch.frac(gt.double().sum((1, 2, 3)) * 0.6180339887).float()
+    metric = P.CallableMetric(fake_distance)
+    many2 = P.run_policy(dec, models, clips, [3, 4], [0.35, 0.6, 0.85], metric, max_batch=5, seed=5, bpp_limit=1e9)
+    one2 = P.run_policy(dec, models, clips, [3, 4], [0.35, 0.6, 0.85], metric, max_batch=1, seed=5, bpp_limit=1e9)
+    for k in many2:
+        for a, b in zip(many2[k], one2[k]):
+            assert (a["d"] == b["d"]).all() and a["bits"] == b["bits"] and len(a["d"]) == 30
+            dist = fake_distance(None, clips[k[0]]).numpy()
+            t = 2
+            while t < 30:                                       # replay the reference's rule on the known distances
+                acc = 0
+                while acc < 5 and t + acc < 30 and dist[t + acc] <= a["thr"]:
+                    acc += 1
+                if acc:
+                    assert (a["d"][t:t + acc] == 0).all()
+                    t += acc
+                else:
+                    assert (a["d"][t:t + 2] == 1).all()
+                    t += 2
+            n_mixed += 0 < a["d"][2:].sum() < 28
+    assert n_mixed > 0                                          # the sweeps exercised partial acceptance
     # RD envelope of the sweep: part of the points, sorted along the hull
     env = P.rd_envelope([r["bpp"] for r in many[(0, 3)]], [np.mean([P.cal_psnr(r["x"][t], clips[0][t].numpy())
                                                                      for t in range(30)]) for r in many[(0, 3)]], True)

@@ -194,6 +194,39 @@ def test_conv_f16x3_scaling_and_saturation(L):
     assert rel(nchw(out)[0][:, far], ref[0][:, far]) < 1e-5
 
 
+@pytest.mark.parametrize("K,H", [(1, 32), (3, 16)])
+def test_conv_f16x3_on_raw_input_with_moment_bound(L, K, H):
+    """EVC_ARITH_F16X3 on an input no GroupNorm has normalised (1x1 skip convolutions, NIN output projections): the
+    element bound comes from the tensor's per-channel moments (evc_gn_coeffs_bound_f32 / evc_moments_bound_f32), the
+    kernel scales by the matching power of two.  Inputs of very different magnitudes -- 1e-5 ... 1e+5, far outside
+    what the unscaled fp16 split could represent -- reach the accuracy of the bf16x6 path."""
+    B, W, C0, C1, Co = 2, H, 64, 32, 192
+    w = (rnd(80, Co, C0 + C1, K, K) / np.sqrt((C0 + C1) * K * K)).cuda()
+    wp = L.conv_pack_weights(w, L.ARITH_F16X3)
+    for mag in (1.0, 1e-5, 1e5):
+        x0, x1 = (rnd(81, B, C0, H, W) * mag).cuda(), (rnd(82, B, C1, H, W) * mag * 7).cuda()
+        x0[1, 5, 3, 3] = 40 * mag                       # an outlier well inside the bound
+        n0, n1 = nhwc(x0), nhwc(x1)
+        bound = torch.zeros(1, dtype=torch.int32, device="cuda")
+        L.gn_coeffs([L.chan_stats(n0), L.chan_stats(n1)], H * W, 32, 1e-5, bound=bound)
+        bval = float(bound.view(torch.float32).sqrt())
+        assert bval >= float(torch.cat([x0, x1], 1).abs().max()) > 0          # it IS a bound on every element
+        ref = F.conv2d(torch.cat([x0, x1], 1).double(), w.double(), None, padding=K // 2)
+        out = L.conv2d_nhwc(n0, wp, Co, K, K, src1=n1, in_bound=bound)
+        e16 = float((nchw(out).double() - ref).abs().max() / ref.abs().max())
+        out6 = L.conv2d_nhwc(n0, L.conv_pack_weights(w, L.ARITH_BF16X6), Co, K, K, src1=n1)
+        e6 = float((nchw(out6).double() - ref).abs().max() / ref.abs().max())
+        assert e16 < 2e-6 and e16 <= 2.0 * e6 + 2e-7, (mag, e16, e6)
+    # the bound of a channel range of one moments tensor (the value third of a q|k|v tensor)
+    qkv = nhwc(torch.cat([x0 * 1e3, x0, x1[:, :32] * 3], 1))          # channels 0..63 huge, 64..159 moderate
+    b2 = torch.zeros(1, dtype=torch.int32, device="cuda")
+    L.moments_bound(L.chan_stats(qkv), 64, 96, b2)
+    assert float(b2.view(torch.float32).sqrt()) >= float(qkv[..., 64:].abs().max())
+    assert float(b2.view(torch.float32).sqrt()) < float(qkv[..., :64].abs().max())      # the other channels do not count
+    with pytest.raises(L.EvcKernelError):        # only the fp16 split scales its input
+        L.conv2d_nhwc(n0, L.conv_pack_weights(w, L.ARITH_BF16X6), Co, K, K, src1=n1, in_bound=bound)
+
+
 def test_conv_rejects_bad_arguments(L):
     x = torch.zeros(1, 4, 4, 24, device="cuda")   # 24 channels: not a multiple of 16
     w = torch.zeros(64 * 2 * 16, device="cuda")
