@@ -171,6 +171,226 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_kernel(const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same attention on the fp16 matrix cores ("f16x3", see csrc/conv_igemm.hip): every operand -- Q, K, V and the
+// softmax weights P -- is scaled by a power of two into fp16's range (Q / K / V from an element bound the caller derives
+// from the q|k|v tensor's moments, P in [0, 1] by 2^10), split 2-way into fp16 (2^-22 relative) and each product runs as
+// three v_mfma_f32_32x32x16_f16 with fp32 accumulation: 72 MFMAs of 32 cycles per 32-key tile and wave instead of 192 of
+// 64 cycles on the f32 pipe.  Same orientation as attention_kernel (S^T = K Q^T, O^T = V^T P^T: the query is the lane,
+// softmax state lane-local).  P feeds the second product straight from the S^T accumulator registers: registers
+// 8s..8s+7 of a 32x32 accumulator are the B fragment of k-step s with the key order permuted to
+// key = 16s + 8(j>>2) + 4*half + (j&3); V is staged TRANSPOSED ([d][key position], fp16 planes) with the keys stored in
+// exactly that order, so its A fragment is one 16-byte LDS read.  K is staged [key][d].  Row pitches are an odd number of
+// 16-byte slots (conflict-free ds_read_b128).
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float pow2_scale_for(float bound_sq_bits_as_float, int target_exp) {
+    const float b = sqrtf(bound_sq_bits_as_float);
+    return (b > 0.f && b < 3.0e38f) ? ldexpf(1.0f, target_exp - ilogbf(b)) : 1.0f;
+}
+
+__device__ __forceinline__ void split2h(float v, _Float16& a, _Float16& b) {
+    v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+    a = (_Float16)v;
+    b = (_Float16)(v - (float)a);
+}
+
+template <int D, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void attention_f16_kernel(const float* __restrict__ q,
+                                                                      const float* __restrict__ k,
+                                                                      const float* __restrict__ v, int ld,
+                                                                      float* __restrict__ out, int ld_out, int N,
+                                                                      float scale, const unsigned* __restrict__ bounds,
+                                                                      int kparts, int tiles_per_part,
+                                                                      float* __restrict__ part_o,
+                                                                      float* __restrict__ part_ml) {
+    constexpr int NKS = D / 16;            // k-steps of the QK^T product
+    constexpr int DT = D / 32;             // 32-wide d tiles of the PV product
+    constexpr int NT = 64 * WAVES;
+    constexpr int KROW = 2 * D + 16;       // bytes per key row of a K plane: D/8 + 1 slots (odd)
+    constexpr int VROW = 64 + 16;          // bytes per d row of a V^T plane: 32 key positions + 1 slot
+    constexpr int KPL = 32 * KROW, VPL = D * VROW;
+    extern __shared__ __attribute__((aligned(16))) char smem_h[];
+    char* const Ks = smem_h;               // [2 planes][32 keys][KROW]
+    char* const Vs = smem_h + 2 * KPL;     // [2 planes][D][VROW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int kpart = kparts > 1 ? blockIdx.x % kparts : 0;
+    const int qblk = kparts > 1 ? blockIdx.x / kparts : blockIdx.x;
+    const int k_begin = kpart * tiles_per_part * 32;
+    const int k_end = kparts > 1 ? min(N, k_begin + tiles_per_part * 32) : N;
+    const int q0 = qblk * 32 * WAVES + wave * 32;
+    const size_t base = (size_t)b * N * ld + (size_t)h * D;
+    const int myq = q0 + l31;
+    const bool qvalid = myq < N;
+
+    // operand scales (powers of two): bound * scale in [2^9, 2^10) -> at most 1024, far above fp16's subnormals
+    const float sq = pow2_scale_for(__uint_as_float(bounds[0]), 9);
+    const float sk = pow2_scale_for(__uint_as_float(bounds[1]), 9);
+    const float sv = pow2_scale_for(__uint_as_float(bounds[2]), 9);
+    constexpr float SP = 1024.0f;                     // softmax weights are in [0, 1]
+    const float s_mul = scale / (sq * sk);            // accumulator -> logits
+    const float o_mul = 1.0f / (SP * sv);             // accumulator -> sum_k p_k v_k
+
+    // Q fragments (B operand of S^T = K Q^T): lane (query l31, half) holds Q[q][16s + 8*half + j], both fp16 planes
+    h16x8 q1[NKS], q2[NKS];
+    {
+        const float* qp = q + base + (size_t)(qvalid ? myq : 0) * ld + 8 * half;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+            if (qvalid) {
+                a = *reinterpret_cast<const float4*>(qp + 16 * s);
+                c = *reinterpret_cast<const float4*>(qp + 16 * s + 4);
+            }
+            const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { _Float16 u, w; split2h(x[j] * sq, u, w); q1[s][j] = u; q2[s][j] = w; }
+        }
+    }
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // LDS fragment offsets (bytes)
+    const int k_rd = l31 * KROW + 16 * half;                      // + plane * KPL + 32 * s
+    const int v_rd = l31 * VROW + 16 * half;                      // + plane * VPL + 32 * t * VROW + 32 * s2
+
+    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+        __syncthreads();   // previous tile fully consumed
+        // ---- stage K: unit = (key, 8-channel chunk) -> two 16-byte writes (one per plane) ----
+        for (int u = tid; u < 32 * (D / 8); u += NT) {
+            const int row = u / (D / 8), ch = u - row * (D / 8);
+            const int key = k0 + row;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+            if (key < N) {
+                const float* kp = k + base + (size_t)key * ld + 8 * ch;
+                a = *reinterpret_cast<const float4*>(kp);
+                c = *reinterpret_cast<const float4*>(kp + 4);
+            }
+            const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+            h16x8 p1, p2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { _Float16 uu, ww; split2h(x[j] * sk, uu, ww); p1[j] = uu; p2[j] = ww; }
+            char* dst = Ks + row * KROW + 16 * ch;
+            *reinterpret_cast<h16x8*>(dst) = p1;
+            *reinterpret_cast<h16x8*>(dst + KPL) = p2;
+        }
+        // ---- stage V transposed: unit = (group of 4 consecutive keys, channel d); lanes run along d (coalesced rows) ----
+        for (int u = tid; u < 8 * D; u += NT) {
+            const int g = u / D, d = u - g * D;
+            float x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = k0 + 4 * g + i;
+                x[i] = key < N ? v[base + (size_t)key * ld + d] : 0.f;
+            }
+            h16x4 p1, p2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { _Float16 uu, ww; split2h(x[i] * sv, uu, ww); p1[i] = uu; p2[i] = ww; }
+            // keys 4g .. 4g+3 sit at positions 16*(g>>2) + 8*(g&1) + 4*((g>>1)&1) + (0..3)
+            const int pos = 16 * (g >> 2) + 8 * (g & 1) + 4 * ((g >> 1) & 1);
+            char* dst = Vs + d * VROW + 2 * pos;
+            *reinterpret_cast<h16x4*>(dst) = p1;
+            *reinterpret_cast<h16x4*>(dst + VPL) = p2;
+        }
+        __syncthreads();
+
+        // ---- S^T tile: rows = keys (registers), col = query (lane) ----
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < NKS; ++st) {
+            const h16x8 k1 = *reinterpret_cast<const h16x8*>(Ks + k_rd + 32 * st);
+            const h16x8 k2 = *reinterpret_cast<const h16x8*>(Ks + KPL + k_rd + 32 * st);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k2, q1[st], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, q2[st], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, q1[st], s, 0, 0, 0);
+        }
+
+        // ---- online softmax over this tile's 32 keys (16 here, 16 in lane ^ 32) ----
+        float m_tile = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            s[r] = key < N ? s[r] * s_mul : -INFINITY;
+            m_tile = fmaxf(m_tile, s[r]);
+        }
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        const float m_new = fmaxf(m_run, m_tile);      // finite: every tile holds at least one valid key
+        const float alpha = __expf(m_run - m_new);     // exp(-inf) = 0 on the first tile
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __expf(s[r] - m_new);
+            psum += s[r];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        if (__any(alpha != 1.0f)) {                    // wave-uniform: once the running maxima settle, no rescale
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
+
+        // ---- O^T += V^T P^T: k-step s2 takes accumulator registers 8*s2 .. 8*s2+7 as its B fragment ----
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            h16x8 p1, p2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { _Float16 uu, ww; split2h(s[8 * s2 + j] * SP, uu, ww); p1[j] = uu; p2[j] = ww; }
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const h16x8 v1 = *reinterpret_cast<const h16x8*>(Vs + v_rd + 32 * t * VROW + 32 * s2);
+                const h16x8 v2 = *reinterpret_cast<const h16x8*>(Vs + VPL + v_rd + 32 * t * VROW + 32 * s2);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v2, p1, o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, p2, o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, p1, o[t], 0, 0, 0);
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    if (kparts > 1) {
+        if (qvalid) {
+            const size_t heads = gridDim.y, B = gridDim.z;
+            float* op = part_o + (((size_t)kpart * B + b) * N + myq) * (heads * D) + (size_t)h * D;
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(op + 32 * t + 8 * g + 4 * half) =
+                        make_float4(o[t][4 * g] * o_mul, o[t][4 * g + 1] * o_mul, o[t][4 * g + 2] * o_mul, o[t][4 * g + 3] * o_mul);
+            if (half == 0) {
+                float* ml = part_ml + ((((size_t)kpart * B + b) * heads + h) * N + myq) * 2;
+                ml[0] = m_run; ml[1] = l_tot;
+            }
+        }
+        return;
+    }
+    const float inv = o_mul / l_tot;
+    if (qvalid) {
+        float* op = out + ((size_t)b * N + myq) * ld_out + (size_t)h * D;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 w = make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv,
+                                       o[t][4 * g + 3] * inv);
+                *reinterpret_cast<float4*>(op + 32 * t + 8 * g + 4 * half) = w;
+            }
+    }
+}
+
 // out[b][n][h*D + d] = sum_p w_p * o_p[d] / sum_p w_p * l_p,  w_p = exp(m_p - max_p m_p): the exact online-softmax
 // merge of the key parts (same formula the kernel applies tile by tile).  One thread per (b, n, h, 4 channels).
 __global__ void attention_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
@@ -236,14 +456,25 @@ AttnPlan attention_plan(int B, int heads, int N, bool have_ws) {
 
 template <int D>
 int launch(const float* q, const float* k, const float* v, int ld, float* out, int ld_out, int B, int heads, int N,
-           float scale, float* ws, hipStream_t st) {
+           float scale, float* ws, const unsigned* bounds, hipStream_t st) {
     const size_t lds = (size_t)2 * 32 * (D + 4) * sizeof(float);
     const AttnPlan pl = attention_plan(B, heads, N, ws != nullptr);
     const int waves = pl.waves;
     float* part_o = ws;
     float* part_ml = ws ? ws + (size_t)pl.kparts * B * N * heads * D : nullptr;
     dim3 grid(((N + 32 * waves - 1) / (32 * waves)) * pl.kparts, heads, B);
-    if (waves == 4)
+    if (bounds) {
+        const size_t lds16 = (size_t)2 * 32 * (2 * D + 16) + (size_t)2 * D * 80;
+        if (waves == 4)
+            hipLaunchKernelGGL((attention_f16_kernel<D, 4>), grid, dim3(256), lds16, st, q, k, v, ld, out, ld_out, N, scale,
+                               bounds, pl.kparts, pl.tiles_per_part, part_o, part_ml);
+        else if (waves == 2)
+            hipLaunchKernelGGL((attention_f16_kernel<D, 2>), grid, dim3(128), lds16, st, q, k, v, ld, out, ld_out, N, scale,
+                               bounds, pl.kparts, pl.tiles_per_part, part_o, part_ml);
+        else
+            hipLaunchKernelGGL((attention_f16_kernel<D, 1>), grid, dim3(64), lds16, st, q, k, v, ld, out, ld_out, N, scale,
+                               bounds, pl.kparts, pl.tiles_per_part, part_o, part_ml);
+    } else if (waves == 4)
         hipLaunchKernelGGL((attention_kernel<D, 4>), grid, dim3(256), lds, st, q, k, v, ld, out, ld_out, N, scale,
                            pl.kparts, pl.tiles_per_part, part_o, part_ml);
     else if (waves == 2)
@@ -266,22 +497,23 @@ int launch(const float* q, const float* k, const float* v, int ld, float* out, i
 }  // namespace
 
 static int attention_dispatch(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out,
-                              int B, int heads, int N, int D, float scale, float* ws, void* stream) {
+                              int B, int heads, int N, int D, float scale, float* ws, const unsigned* bounds,
+                              void* stream) {
     if (!q || !k || !v || !out || B <= 0 || heads <= 0 || N <= 0 || ld_qkv < heads * D || ld_out < heads * D)
         return EVC_EINVAL;
     if ((ld_qkv & 3) || (ld_out & 3)) return EVC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     switch (D) {
-        case 192: return launch<192>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, ws, st);
-        case 64: return launch<64>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, ws, st);
-        case 32: return launch<32>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, ws, st);
+        case 192: return launch<192>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, ws, bounds, st);
+        case 64: return launch<64>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, ws, bounds, st);
+        case 32: return launch<32>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, ws, bounds, st);
         default: return EVC_EUNSUPPORTED;
     }
 }
 
 extern "C" int evc_attention_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out,
                                  int B, int heads, int N, int D, float scale, void* stream) {
-    return attention_dispatch(q, k, v, ld_qkv, out, ld_out, B, heads, N, D, scale, nullptr, stream);
+    return attention_dispatch(q, k, v, ld_qkv, out, ld_out, B, heads, N, D, scale, nullptr, nullptr, stream);
 }
 
 extern "C" long long evc_attention_workspace_bytes(int B, int heads, int N, int D) {
@@ -294,5 +526,13 @@ extern "C" long long evc_attention_workspace_bytes(int B, int heads, int N, int 
 extern "C" int evc_attention_ws_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out,
                                     int B, int heads, int N, int D, float scale, float* ws, void* stream) {
     if (evc_attention_workspace_bytes(B, heads, N, D) > 0 && !ws) return EVC_EINVAL;
-    return attention_dispatch(q, k, v, ld_qkv, out, ld_out, B, heads, N, D, scale, ws, stream);
+    return attention_dispatch(q, k, v, ld_qkv, out, ld_out, B, heads, N, D, scale, ws, nullptr, stream);
+}
+
+extern "C" int evc_attention_f16x3_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out,
+                                       int B, int heads, int N, int D, float scale, const unsigned* bounds, float* ws,
+                                       void* stream) {
+    if (!bounds) return EVC_EINVAL;
+    if (evc_attention_workspace_bytes(B, heads, N, D) > 0 && !ws) return EVC_EINVAL;
+    return attention_dispatch(q, k, v, ld_qkv, out, ld_out, B, heads, N, D, scale, ws, bounds, stream);
 }

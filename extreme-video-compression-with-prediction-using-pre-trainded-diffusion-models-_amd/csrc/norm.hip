@@ -127,11 +127,12 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(CoefArgs a) {
     }
 }
 
-// max over a channel range of a moments tensor [B][nsplit][C][2]: the bound of a tensor that has no GroupNorm in
-// front of it (evc_moments_bound_f32).  grid (nsplit, B).
+// max over channel ranges of a moments tensor [B][nsplit][C][2]: the bound of a tensor that has no GroupNorm in
+// front of it (evc_moments_bound_f32).  grid (nsplit, B, ranges): range z = channels [c_begin + z*c_count, +c_count).
 __global__ __launch_bounds__(256) void moments_bound_kernel(const float* __restrict__ part, int nsplit, int C, int c_begin,
                                                             int c_count, unsigned* __restrict__ bound_bits) {
-    const float* row = part + ((size_t)(blockIdx.y * nsplit + blockIdx.x) * C + c_begin) * 2;
+    const float* row = part + ((size_t)(blockIdx.y * nsplit + blockIdx.x) * C + c_begin + blockIdx.z * c_count) * 2;
+    bound_bits += blockIdx.z;
     float mx = 0.f;
     for (int i = threadIdx.x; i < c_count; i += 256) mx = fmaxf(mx, row[2 * i + 1]);
 #pragma unroll
@@ -190,11 +191,12 @@ extern "C" int evc_gn_coeffs_f32(const float* part0, int nsplit0, int C0, const 
                                    ss_ld, row, coef_a, coef_s, nullptr, stream);
 }
 
-extern "C" int evc_moments_bound_f32(const float* part, int nsplit, int C, int c_begin, int c_count, int B,
+extern "C" int evc_moments_bound_f32(const float* part, int nsplit, int C, int c_begin, int c_count, int n_ranges, int B,
                                      unsigned* bound_bits, void* stream) {
-    if (!part || !bound_bits || nsplit <= 0 || C <= 0 || B <= 0 || c_begin < 0 || c_count <= 0 || c_begin + c_count > C)
+    if (!part || !bound_bits || nsplit <= 0 || C <= 0 || B <= 0 || c_begin < 0 || c_count <= 0 || n_ranges <= 0 ||
+        c_begin + (long long)n_ranges * c_count > C)
         return EVC_EINVAL;
-    hipLaunchKernelGGL(moments_bound_kernel, dim3(nsplit, B), dim3(256), 0, (hipStream_t)stream, part, nsplit, C,
+    hipLaunchKernelGGL(moments_bound_kernel, dim3(nsplit, B, n_ranges), dim3(256), 0, (hipStream_t)stream, part, nsplit, C,
                        c_begin, c_count, bound_bits);
     return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
 }

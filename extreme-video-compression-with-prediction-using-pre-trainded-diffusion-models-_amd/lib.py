@@ -85,7 +85,9 @@ HIP_SYMBOLS = {
     "evc_gn_coeffs_bound_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                         c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p]),
-    "evc_moments_bound_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "evc_moments_bound_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "evc_attention_f16x3_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                        c_float, c_void_p, c_void_p, c_void_p]),
     "evc_affine_act_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_void_p]),
     "evc_conv_co_pad": (c_int, [c_int]),
@@ -286,18 +288,20 @@ def gn_coeffs(parts, HW, groups, eps, mode=0, gamma=None, beta=None, ss=None, ro
     return ca, cs
 
 
-def _word(t):
-    """Device pointer of a one-element int32 tensor (or view), None when absent."""
+def _word(t, n=1):
+    """Device pointer of an n-element int32 tensor (or view), None when absent."""
     if t is None:
         return None
-    assert t.is_cuda and t.dtype == torch.int32 and t.numel() == 1
+    assert t.is_cuda and t.dtype == torch.int32 and t.numel() == n and t.is_contiguous()
     return c_void_p(t.data_ptr())
 
 
 def moments_bound(part, c_begin, c_count, bound):
-    """Raise ``bound`` to the element bound of channels [c_begin, c_begin + c_count) of a moments tensor (B, ns, C, 2)."""
+    """Raise ``bound[z]`` to the element bound of channels [c_begin + z*c_count, + c_count) of a moments tensor
+    (B, ns, C, 2), for z < bound.numel()."""
     B, ns, C, _ = part.shape
-    _check(hip_lib().evc_moments_bound_f32(fptr(part), ns, C, c_begin, c_count, B, _word(bound), stream_ptr()),
+    n = bound.numel()
+    _check(hip_lib().evc_moments_bound_f32(fptr(part), ns, C, c_begin, c_count, n, B, _word(bound, n), stream_ptr()),
            "evc_moments_bound_f32")
 
 
@@ -442,8 +446,9 @@ def conv_fused_stats_splits(B, H, W, Ci, Co, KH, KW, splits=0, arith=None):
     return hip_lib(require_device=False).evc_conv_stats_splits(ctypes.byref(a))
 
 
-def attention(qkv, C, heads, out=None):
-    """qkv: (B, N, 3C) with q | k | v concatenated along channels; returns (B, N, C)."""
+def attention(qkv, C, heads, out=None, bounds=None):
+    """qkv: (B, N, 3C) with q | k | v concatenated along channels; returns (B, N, C).  ``bounds``: three int32 words
+    (element bounds of q, k, v from ``moments_bound``) select the fp16-split kernel; None the f32-MFMA one."""
     L = hip_lib()
     B, N, ld = qkv.shape
     D = C // heads
@@ -452,6 +457,11 @@ def attention(qkv, C, heads, out=None):
     base = qkv.data_ptr()
     nbytes = L.evc_attention_workspace_bytes(B, heads, N, D)
     ws = _workspace(nbytes, qkv.device) if nbytes > 0 else None      # stream-ordered: shared with the conv workspace
+    if bounds is not None:
+        _check(L.evc_attention_f16x3_f32(c_void_p(base), c_void_p(base + 4 * C), c_void_p(base + 8 * C), ld, fptr(out), C,
+                                         B, heads, N, D, float(int(D) ** (-0.5)), _word(bounds, 3), ptr(ws), stream_ptr()),
+               "evc_attention_f16x3_f32")
+        return out
     _check(L.evc_attention_ws_f32(c_void_p(base), c_void_p(base + 4 * C), c_void_p(base + 8 * C), ld, fptr(out), C, B,
                                   heads, N, D, float(int(D) ** (-0.5)), ptr(ws), stream_ptr()), "evc_attention_ws_f32")
     return out

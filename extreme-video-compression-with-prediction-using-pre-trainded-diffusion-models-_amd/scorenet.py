@@ -259,12 +259,12 @@ class ScoreNet:
         return L.gn_coeffs(parts, hw, num_groups(ch), 1e-5, mode=2, ss=self._table[:, off:off + 2 * c], row=rows,
                            bound=bound)
 
-    def _bound_slot(self):
-        """A zeroed device word of this forward's arena (element bounds for fp16-split convolutions on raw inputs)."""
+    def _bound_slot(self, n=1):
+        """n zeroed device words of this forward's arena (element bounds for the fp16-split kernels on raw inputs)."""
         if not self._f16_raw:
             return None
-        w = self._bounds[self._bound_next:self._bound_next + 1]
-        self._bound_next += 1
+        w = self._bounds[self._bound_next:self._bound_next + n]
+        self._bound_next += n
         return w
 
     def _res(self, i, m, x, skip, rows):
@@ -317,13 +317,17 @@ class ScoreNet:
         hd = self.d.n_head_channels
         heads = 1 if C < hd else C // hd
         coef = L.gn_coeffs([x.stats()], H * W, num_groups(C), 1e-6, mode=1, gamma=e["gamma"], beta=e["beta"])
-        obound = self._bound_slot()
-        if obound is None:
+        qkvb = self._bound_slot(3)
+        if qkvb is None:
+            obound = None
             qkv = L.conv2d_nhwc(x.t, e["wqkv"], 3 * C, 1, 1, bias=e["bqkv"], coef=coef)
-        else:       # the attention output is a convex combination of value rows: max |o| <= max |v| <= sqrt(bound of v)
+        else:
+            # element bounds of q, k, v from the projection's fused moments (one small launch); the attention output is
+            # a convex combination of value rows, so max |o| <= max |v|: v's bound also serves the output projection
             qkv, qst = L.conv2d_nhwc(x.t, e["wqkv"], 3 * C, 1, 1, bias=e["bqkv"], coef=coef, want_stats=True)
-            L.moments_bound(qst, 2 * C, C, obound)
-        o = L.attention(qkv.view(B, H * W, 3 * C), C, heads)
+            L.moments_bound(qst, 0, C, qkvb)
+            obound = qkvb[2:3]
+        o = L.attention(qkv.view(B, H * W, 3 * C), C, heads, bounds=qkvb)
         return _Act(*L.conv2d_nhwc(o.view(B, H, W, C), e["wo"], C, 1, 1, bias=e["bo"], res=x.t,
                                    out_scale=INV_SQRT2, want_stats=True, in_bound=obound))
 
@@ -337,7 +341,7 @@ class ScoreNet:
             key = torch.cuda.current_stream().cuda_stream
             self._bounds = self._bounds_by_stream.get(key)
             if self._bounds is None:
-                self._bounds = self._bounds_by_stream[key] = torch.zeros(128, device=self.device, dtype=torch.int32)
+                self._bounds = self._bounds_by_stream[key] = torch.zeros(256, device=self.device, dtype=torch.int32)
             self._bounds.zero_()          # one memset per forward; slots are handed out in program order
             self._bound_next = 0
         i = 2

@@ -94,10 +94,11 @@ int evc_gn_coeffs_bound_f32(const float* part0, int nsplit0, int C0, const float
                             int HW, int groups, float eps, int mode, const float* gamma, const float* beta,
                             const float* ss, int ss_ld, const int* row, float* coef_a, float* coef_s,
                             unsigned* bound_bits, void* stream);
-/* The same bound over channels [c_begin, c_begin + c_count) of one moments tensor [B][nsplit][C][2] (for tensors that are
- * not followed by a GroupNorm, e.g. the value projection feeding attention). */
-int evc_moments_bound_f32(const float* part, int nsplit, int C, int c_begin, int c_count, int B, unsigned* bound_bits,
-                          void* stream);
+/* The same bound over n_ranges consecutive channel ranges [c_begin + z*c_count, + c_count) of one moments tensor
+ * [B][nsplit][C][2], range z into bound_bits[z] (for tensors that are not followed by a GroupNorm: the q | k | v
+ * projection feeding attention has three). */
+int evc_moments_bound_f32(const float* part, int nsplit, int C, int c_begin, int c_count, int n_ranges, int B,
+                          unsigned* bound_bits, void* stream);
 
 /* y = act(x*coef_a[b][c] + coef_s[b][c]) elementwise on NHWC: the stand-alone form of the fused load.  One pass per
  * tensor instead of once per filter tap inside the convolution (SiLU costs MFMA issue slots there; HBM is cheap).
@@ -172,6 +173,14 @@ int evc_attention_f32(const float* q, const float* k, const float* v, int ld_qkv
 long long evc_attention_workspace_bytes(int B, int heads, int N, int D);
 int evc_attention_ws_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out, int B,
                          int heads, int N, int D, float scale, float* ws, void* stream);
+
+/* The same attention on the fp16 matrix cores (EVC_ARITH_F16X3 scheme: operands scaled by powers of two, 2-way fp16
+ * split, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulation and fp32 softmax).  `bounds` = three device words
+ * holding the bit patterns of floats Sq, Sk, Sv with |q| <= sqrt(Sq), |k| <= sqrt(Sk), |v| <= sqrt(Sv) elementwise
+ * (evc_moments_bound_f32 over the q / k / v channel ranges of the projection's moments).  Same workspace as
+ * evc_attention_ws_f32 (pass NULL when evc_attention_workspace_bytes() is 0). */
+int evc_attention_f16x3_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out, int B,
+                            int heads, int N, int D, float scale, const unsigned* bounds, float* ws, void* stream);
 
 /* ---- sampler steps (elementwise, flat over n floats) ---------------------------------------- */
 /* DDPM ancestral step (models/__init__.py:289-330):

@@ -221,6 +221,10 @@ def test_conv_f16x3_on_raw_input_with_moment_bound(L, K, H):
     qkv = nhwc(torch.cat([x0 * 1e3, x0, x1[:, :32] * 3], 1))          # channels 0..63 huge, 64..159 moderate
     b2 = torch.zeros(1, dtype=torch.int32, device="cuda")
     L.moments_bound(L.chan_stats(qkv), 64, 96, b2)
+    b3 = torch.zeros(2, dtype=torch.int32, device="cuda")           # two consecutive ranges in one launch
+    L.moments_bound(L.chan_stats(qkv), 0, 64, b3)
+    assert float(b3[:1].view(torch.float32).sqrt()) >= float(qkv[..., :64].abs().max())
+    assert float(b3[1:].view(torch.float32).sqrt()) >= float(qkv[..., 64:128].abs().max())
     assert float(b2.view(torch.float32).sqrt()) >= float(qkv[..., 64:].abs().max())
     assert float(b2.view(torch.float32).sqrt()) < float(qkv[..., :64].abs().max())      # the other channels do not count
     with pytest.raises(L.EvcKernelError):        # only the fp16 split scales its input
@@ -327,18 +331,31 @@ def test_upfirdn2d_nhwc_fast_paths_with_an_asymmetric_kernel(L, B, C, H, W):
         np.testing.assert_allclose(nchw(got).cpu().numpy(), O.upfirdn2d(src, k, up=1, down=2, pad=(1, 1)), atol=5e-6)
 
 
+def qkv_bounds(L, qkv, C):
+    """Element bounds of the q | k | v thirds, as ScoreNet derives them from the projection's moments."""
+    B, N, _ = qkv.shape
+    b = torch.zeros(3, dtype=torch.int32, device="cuda")
+    L.moments_bound(L.chan_stats(qkv.view(B, 1, N, 3 * C)), 0, C, b)
+    return b
+
+
+@pytest.fixture(params=[False, True], ids=["f32mfma", "f16x3"])
+def attn_f16(request):
+    return request.param
+
+
 @pytest.mark.parametrize("B,heads,N,D", [(2, 2, 1024, 192), (1, 4, 64, 192), (2, 3, 256, 192), (2, 2, 96, 32), (1, 1, 64, 64)])
-def test_attention(L, B, heads, N, D):
+def test_attention(L, attn_f16, B, heads, N, D):
     C = heads * D
     qkv = rnd(40, B, N, 3 * C).cuda()
-    out = L.attention(qkv, C, heads)
+    out = L.attention(qkv, C, heads, bounds=qkv_bounds(L, qkv, C) if attn_f16 else None)
     q, k, v = [t.reshape(B, N, heads, D).permute(0, 2, 1, 3) for t in qkv.cpu().split(C, dim=2)]
     w = torch.softmax(torch.einsum("bhqd,bhkd->bhqk", q, k) * (D ** -0.5), dim=-1)
     ref = torch.einsum("bhqk,bhkd->bhqd", w, v).permute(0, 2, 1, 3).reshape(B, N, C)
     assert rel(out, ref) < 1e-5
 
 
-def test_attention_peaked_scores_exercise_the_rescale(L):
+def test_attention_peaked_scores_exercise_the_rescale(L, attn_f16):
     """large logits whose maximum moves to later key tiles force the online-softmax rescale branch."""
     B, heads, N, D = 1, 1, 128, 32
     C = D
@@ -346,7 +363,7 @@ def test_attention_peaked_scores_exercise_the_rescale(L):
     k = rnd(42, B, N, C) * torch.linspace(0.5, 6.0, N)[None, :, None]   # later keys dominate
     v = rnd(43, B, N, C)
     qkv = torch.cat([q, k, v], 2).cuda()
-    out = L.attention(qkv, C, heads)
+    out = L.attention(qkv, C, heads, bounds=qkv_bounds(L, qkv, C) if attn_f16 else None)
     w = torch.softmax(torch.einsum("bqd,bkd->bqk", q.double(), k.double()) * (D ** -0.5), dim=-1)
     ref = torch.einsum("bqk,bkd->bqd", w, v.double()).float()
     assert rel(out, ref) < 2e-5
@@ -373,6 +390,10 @@ def test_attention_key_split_matches_single_pass(L):
         assert lib.evc_attention_ws_f32(*args, L.fptr(out_ws), C, B, heads, N, D, D ** -0.5, L.ptr(ws), L.stream_ptr()) == 0
         assert lib.evc_attention_f32(*args, L.fptr(out_1), C, B, heads, N, D, D ** -0.5, L.stream_ptr()) == 0
         assert rel(out_ws, out_1) < 2e-6
+        out_h = torch.empty(B, N, C, device="cuda")             # the fp16-split kernel through the same key split
+        assert lib.evc_attention_f16x3_f32(*args, L.fptr(out_h), C, B, heads, N, D, D ** -0.5,
+                                           L.ptr(qkv_bounds(L, qkv, C)), L.ptr(ws), L.stream_ptr()) == 0
+        assert rel(out_h, out_1) < 5e-6
         if B * N <= 2048:
             qh, kh, vh = [t.double().reshape(B, N, heads, D).permute(0, 2, 1, 3) for t in (q, k, v)]
             w = torch.softmax(torch.einsum("bhqd,bhkd->bhqk", qh, kh) * (D ** -0.5), dim=-1)
