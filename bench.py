@@ -217,31 +217,32 @@ def cpu_baseline_leg(sd_d, sd_e, seconds):
             ON.forward(p, d, x, lab, cond=c)
             n += 1
         return (time.time() - t0) / n, n
-    progress(f"cpu baseline: fp32 oracle forwards at {n_all} threads")
+    # Thread count: torch's default (one per physical core) or 16 -- this box's CPU share can be far smaller than its core
+    # count, and an oversubscribed run is 10-30x slower -- whichever runs a probe forward faster; the bounded sample
+    # (forwards + a short chunk) then runs at that count.
+    cands = [n_all] + ([16] if n_all > 16 else [])
+    probe = {}
+    for n in cands:
+        torch.set_num_threads(n)
+        probe[n], _ = time_forwards(0.0, 1)
+        progress(f"cpu baseline: probe forward at {n} threads: {probe[n]:.2f} s")
+    n_best = min(probe, key=probe.get)
+    torch.set_num_threads(n_best)
     t_all, n_fwd = time_forwards(seconds, 40)
-    progress(f"cpu baseline: {t_all:.2f} s/forward; 2-step DDPM chunk through the oracle sampler")
+    progress(f"cpu baseline: {t_all:.3f} s/forward at {n_best} threads ({n_fwd} forwards); 2-step DDPM chunk through the oracle sampler")
     # a 2-step DDPM chunk = 3 forwards + 2 updates + denoise: the per-step sampler cost beside the forwards
     t0 = time.time()
     OS.ddpm(x.clone(), lambda xx, t: ON.forward(p, d, xx, t, cond=c), OSch.base_schedule(), subsample_steps=2)
     t_chunk3 = time.time() - t0
     step_overhead = max(0.0, (t_chunk3 - 3 * t_all) / 3)
     chunk_all = 101 * (t_all + step_overhead)
-    # the box's CPU share can be smaller than its physical core count: also time a 16-thread run and keep the faster
-    t_16 = None
-    if n_all > 16:
-        torch.set_num_threads(16)
-        t_16, _ = time_forwards(min(seconds, 6.0), 8)
-        torch.set_num_threads(n_all)
-        progress(f"cpu baseline: {t_16:.2f} s/forward at 16 threads")
     progress("cpu baseline: one forward at 1 thread (the reference CLI's setting)")
     torch.set_num_threads(1)
     try:
         got_one = torch.get_num_threads()
         t_one, n_one = time_forwards(0.0, 1, warm=False)       # a single un-warmed forward
     finally:
-        torch.set_num_threads(n_all)
-    t_best, n_best = (t_all, n_all) if t_16 is None or t_all <= t_16 else (t_16, 16)
-    chunk_all = 101 * (t_best + step_overhead)
+        torch.set_num_threads(n_best)
     # one ELIC key-frame decode on the CPU (oracle nets; range coding through the native coder, as compressai's is C++)
     elic_ms = None
     progress(f"cpu baseline: {t_one:.1f} s/forward at 1 thread; one ELIC key-frame decode")
@@ -263,14 +264,15 @@ def cpu_baseline_leg(sd_d, sd_e, seconds):
     clip_s = 6 * chunk_all + 2 * (elic_ms / 1e3 if isinstance(elic_ms, float) else 0.0)
     return {"value": round(30.0 / clip_s, 5), "unit": "frames/s", "cores": n_best, "kind": "port",
             "physical_cores": physical,
-            "sample": f"{n_fwd} fp32 score-network forwards (B=1, 345.2 GFLOP each) at {n_all} threads: {t_all:.3f} s/forward; "
+            "sample": f"{n_fwd} fp32 score-network forwards (B=1, 345.2 GFLOP each) at {n_best} threads: {t_all:.3f} s/forward "
+                      f"(probe forwards: {', '.join(f'{n} threads {t:.2f} s' for n, t in probe.items())}); "
                       f"a 2-step DDPM chunk through the oracle sampler: {t_chunk3:.2f} s (sampler step overhead "
-                      f"{step_overhead * 1e3:.0f} ms/step); at 16 threads: {t_16 if t_16 is None else round(t_16, 3)} s/forward; {n_one} forward at "
+                      f"{step_overhead * 1e3:.0f} ms/step); {n_one} forward at "
                       f"torch.set_num_threads(1) (get_num_threads() = {got_one}; the reference CLI's setting): {t_one:.2f} s; one ELIC key-frame "
                       f"decode: {elic_ms if not isinstance(elic_ms, float) else round(elic_ms, 1)} ms.  value = 30 frames / "
                       f"(6 chunks x 101 x (forward + step) + 2 key-frame decodes) with the fastest thread count ({n_best}), extrapolated "
                       f"from the sample",
-            "forward_s_all_threads": round(t_all, 4), "forward_s_16_threads": None if t_16 is None else round(t_16, 4),
+            "forward_s": round(t_all, 4), "probe_forward_s_by_threads": {str(n): round(t, 3) for n, t in probe.items()},
             "forward_s_1_thread": round(t_one, 3),
             "chunk_s_best_threads": round(chunk_all, 1), "chunk_s_1_thread": round(101 * (t_one + step_overhead), 1),
             "frames_per_s_1_thread": round(30.0 / (6 * 101 * (t_one + step_overhead)), 6),

@@ -263,19 +263,47 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_f16_kernel(const floa
     const int k_rd = l31 * KROW + 16 * half;                      // + plane * KPL + 32 * s
     const int v_rd = l31 * VROW + 16 * half;                      // + plane * VPL + 32 * t * VROW + 32 * s2
 
-    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
-        __syncthreads();   // previous tile fully consumed
-        // ---- stage K: unit = (key, 8-channel chunk) -> two 16-byte writes (one per plane) ----
-        for (int u = tid; u < 32 * (D / 8); u += NT) {
+    // K / V staging with a register prefetch: the global loads of tile t+1 are issued before the MFMAs of tile t and
+    // converted (scale, clamp, 2-way fp16 split) + written to LDS after them, so their latency hides behind the tile's
+    // compute.  K unit = (key, 8-channel chunk): two float4 loads -> two 16-byte LDS writes (one per plane);
+    // V unit = (group of 4 consecutive keys, channel d), lanes along d (coalesced rows) -> two 8-byte writes into the
+    // transposed image at the keys' permuted positions.
+    constexpr int KU = (32 * (D / 8) + NT - 1) / NT;          // K units per thread
+    constexpr int VU = (8 * D + NT - 1) / NT;                 // V units per thread
+    float4 kreg[KU][2];
+    float vreg[VU][4];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < KU; ++i) {
+            const int u = tid + NT * i;
             const int row = u / (D / 8), ch = u - row * (D / 8);
             const int key = k0 + row;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-            if (key < N) {
+            kreg[i][0] = kreg[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < 32 * (D / 8) && key < N) {
                 const float* kp = k + base + (size_t)key * ld + 8 * ch;
-                a = *reinterpret_cast<const float4*>(kp);
-                c = *reinterpret_cast<const float4*>(kp + 4);
+                kreg[i][0] = *reinterpret_cast<const float4*>(kp);
+                kreg[i][1] = *reinterpret_cast<const float4*>(kp + 4);
             }
-            const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        }
+#pragma unroll
+        for (int i = 0; i < VU; ++i) {
+            const int u = tid + NT * i;
+            const int g = u / D, d = u - g * D;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = k0 + 4 * g + e;
+                vreg[i][e] = (u < 8 * D && key < N) ? v[base + (size_t)key * ld + d] : 0.f;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < KU; ++i) {
+            const int u = tid + NT * i;
+            if (u >= 32 * (D / 8)) break;
+            const int row = u / (D / 8), ch = u - row * (D / 8);
+            const float x[8] = {kreg[i][0].x, kreg[i][0].y, kreg[i][0].z, kreg[i][0].w,
+                                kreg[i][1].x, kreg[i][1].y, kreg[i][1].z, kreg[i][1].w};
             h16x8 p1, p2;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { _Float16 uu, ww; split2h(x[j] * sk, uu, ww); p1[j] = uu; p2[j] = ww; }
@@ -283,25 +311,28 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_f16_kernel(const floa
             *reinterpret_cast<h16x8*>(dst) = p1;
             *reinterpret_cast<h16x8*>(dst + KPL) = p2;
         }
-        // ---- stage V transposed: unit = (group of 4 consecutive keys, channel d); lanes run along d (coalesced rows) ----
-        for (int u = tid; u < 8 * D; u += NT) {
-            const int g = u / D, d = u - g * D;
-            float x[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int key = k0 + 4 * g + i;
-                x[i] = key < N ? v[base + (size_t)key * ld + d] : 0.f;
-            }
+        for (int i = 0; i < VU; ++i) {
+            const int u = tid + NT * i;
+            if (u >= 8 * D) break;
+            const int g = u / D, d = u - g * D;
             h16x4 p1, p2;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { _Float16 uu, ww; split2h(x[i] * sv, uu, ww); p1[i] = uu; p2[i] = ww; }
+            for (int e = 0; e < 4; ++e) { _Float16 uu, ww; split2h(vreg[i][e] * sv, uu, ww); p1[e] = uu; p2[e] = ww; }
             // keys 4g .. 4g+3 sit at positions 16*(g>>2) + 8*(g&1) + 4*((g>>1)&1) + (0..3)
             const int pos = 16 * (g >> 2) + 8 * (g & 1) + 4 * ((g >> 1) & 1);
             char* dst = Vs + d * VROW + 2 * pos;
             *reinterpret_cast<h16x4*>(dst) = p1;
             *reinterpret_cast<h16x4*>(dst + VPL) = p2;
         }
+    };
+
+    if (k_begin < k_end) load_tile(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+        __syncthreads();   // previous tile fully consumed
+        store_tile();
         __syncthreads();
+        if (k0 + 32 < k_end) load_tile(k0 + 32);       // in flight during this tile's MFMAs
 
         // ---- S^T tile: rows = keys (registers), col = query (lane) ----
         f32x16 s;
@@ -454,16 +485,33 @@ AttnPlan attention_plan(int B, int heads, int N, bool have_ws) {
     return p;
 }
 
+// The fp16 kernel converts every K / V tile on the fly (scale, split, transpose), a cost shared by the waves of a
+// workgroup: always the largest workgroup the query count fills, then key parts until the launch offers ~2 per CU.
+AttnPlan attention_plan_f16(int B, int heads, int N) {
+    AttnPlan p;
+    const long long bh = (long long)B * heads;
+    const int ntiles = (N + 31) / 32;
+    p.waves = N >= 128 ? 4 : (N >= 64 ? 2 : 1);
+    const long long qblocks = (N + 32 * p.waves - 1) / (32 * p.waves);
+    p.kparts = 1;
+    while (p.kparts < 8 && bh * qblocks * p.kparts < EVC_ATTN_WG_TARGET && ntiles / (p.kparts * 2) >= 2) p.kparts *= 2;
+    p.tiles_per_part = (ntiles + p.kparts - 1) / p.kparts;
+    p.kparts = (ntiles + p.tiles_per_part - 1) / p.tiles_per_part;
+    return p;
+}
+
 template <int D>
 int launch(const float* q, const float* k, const float* v, int ld, float* out, int ld_out, int B, int heads, int N,
            float scale, float* ws, const unsigned* bounds, hipStream_t st) {
     const size_t lds = (size_t)2 * 32 * (D + 4) * sizeof(float);
-    const AttnPlan pl = attention_plan(B, heads, N, ws != nullptr);
+    const AttnPlan pl = (bounds && ws && N >= 128) ? attention_plan_f16(B, heads, N) : attention_plan(B, heads, N, ws != nullptr);
     const int waves = pl.waves;
     float* part_o = ws;
     float* part_ml = ws ? ws + (size_t)pl.kparts * B * N * heads * D : nullptr;
     dim3 grid(((N + 32 * waves - 1) / (32 * waves)) * pl.kparts, heads, B);
-    if (bounds) {
+    // tiny key sets (N < 128: the 8x8 level) stay on the f32 kernel: with two key tiles there is nothing to amortise the
+    // fp16 conversion of K / V over (measured B=9, 8x8: 26 us f32 vs 39 us fp16 split; 16x16: 81 vs 29; 32x32: 260 vs 155)
+    if (bounds && N >= 128) {
         const size_t lds16 = (size_t)2 * 32 * (2 * D + 16) + (size_t)2 * D * 80;
         if (waves == 4)
             hipLaunchKernelGGL((attention_f16_kernel<D, 4>), grid, dim3(256), lds16, st, q, k, v, ld, out, ld_out, N, scale,
@@ -518,9 +566,10 @@ extern "C" int evc_attention_f32(const float* q, const float* k, const float* v,
 
 extern "C" long long evc_attention_workspace_bytes(int B, int heads, int N, int D) {
     if (B <= 0 || heads <= 0 || N <= 0 || D <= 0) return EVC_EINVAL;
-    const AttnPlan pl = attention_plan(B, heads, N, true);
-    if (pl.kparts <= 1) return 0;
-    return (long long)pl.kparts * B * N * heads * ((long long)D + 2) * (long long)sizeof(float);
+    const int kp = attention_plan(B, heads, N, true).kparts, kp16 = attention_plan_f16(B, heads, N).kparts;
+    const int kparts = kp > kp16 ? kp : kp16;          // one workspace serves both kernels
+    if (kparts <= 1) return 0;
+    return (long long)kparts * B * N * heads * ((long long)D + 2) * (long long)sizeof(float);
 }
 
 extern "C" int evc_attention_ws_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out,
