@@ -88,6 +88,9 @@ HIP_SYMBOLS = {
     "evc_moments_bound_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "evc_attention_f16x3_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_float, c_void_p, c_void_p, c_void_p]),
+    "evc_gdn_workspace_bytes": (c_longlong, [c_int, c_int, c_int, c_int]),
+    "evc_gdn_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                            c_int, c_void_p]),
     "evc_affine_act_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_void_p]),
     "evc_conv_co_pad": (c_int, [c_int]),
@@ -465,6 +468,38 @@ def attention(qkv, C, heads, out=None, bounds=None):
     _check(L.evc_attention_ws_f32(c_void_p(base), c_void_p(base + 4 * C), c_void_p(base + 8 * C), ld, fptr(out), C, B,
                                   heads, N, D, float(int(D) ** (-0.5)), ptr(ws), stream_ptr()), "evc_attention_ws_f32")
     return out
+
+
+class GDN:
+    """GDN / IGDN / GDN1 (reference ELICUtilis/layers/gdn.py:26-106) on NHWC tensors.  ``beta`` (C,) and ``gamma`` (C, C)
+    are the RAW parameters of the reference module; compressai's NonNegativeParametrizer is applied here, once:
+    ``max(p, sqrt(minimum + 2^-36))^2 - 2^-36`` (minimum = beta_min for beta, 0 for gamma)."""
+    PEDESTAL = (2.0 ** -18) ** 2
+
+    def __init__(self, beta, gamma, inverse=False, simplified=False, beta_min=1e-6, device="cuda"):
+        hip_lib()
+        b = beta.detach().to(device, torch.float32)
+        g = gamma.detach().to(device, torch.float32)
+        self.C = b.numel()
+        self.beta = (torch.clamp(b, min=(beta_min + self.PEDESTAL) ** 0.5) ** 2 - self.PEDESTAL).contiguous()
+        gm = torch.clamp(g, min=self.PEDESTAL ** 0.5) ** 2 - self.PEDESTAL
+        self.arith = default_arith()
+        self.gamma = conv_pack_weights(gm.reshape(self.C, self.C, 1, 1).contiguous(), self.arith)
+        self.inverse, self.simplified = bool(inverse), bool(simplified)
+
+    def __call__(self, x, out=None):
+        B, H, W, C = x.shape
+        assert C == self.C and x.dtype == torch.float32
+        Lh = hip_lib()
+        nbytes = Lh.evc_gdn_workspace_bytes(B, H, W, C)
+        if nbytes < 0:
+            raise EvcKernelError(f"evc_gdn_workspace_bytes rejected the arguments ({nbytes})")
+        ws = _workspace(nbytes, x.device)
+        if out is None:
+            out = torch.empty_like(x)
+        _check(Lh.evc_gdn_f32(fptr(x), ptr(self.gamma), self.arith, fptr(self.beta), fptr(out), ptr(ws), B, H, W, C,
+                              int(self.inverse), int(self.simplified), stream_ptr()), "evc_gdn_f32")
+        return out
 
 
 def ddpm_step(x, e, noise, k1, k2, c1, c2, sigma, clip):

@@ -338,10 +338,16 @@ class ScoreNet:
         prog = self.program
         B, _, H, W = x.shape
         if self._f16_raw:
-            key = torch.cuda.current_stream().cuda_stream
-            self._bounds = self._bounds_by_stream.get(key)
-            if self._bounds is None:
-                self._bounds = self._bounds_by_stream[key] = torch.zeros(256, device=self.device, dtype=torch.int32)
+            # one arena per stream (concurrent clip groups run their forwards on their own streams).  Inside a HIP-graph
+            # capture every graph owns its arena: all captures share one capture stream, and graphs replayed
+            # concurrently on different streams would race on a shared one.
+            if torch.cuda.is_current_stream_capturing():
+                self._bounds = torch.empty(256, device=self.device, dtype=torch.int32)
+            else:
+                key = torch.cuda.current_stream().cuda_stream
+                self._bounds = self._bounds_by_stream.get(key)
+                if self._bounds is None:
+                    self._bounds = self._bounds_by_stream[key] = torch.empty(256, device=self.device, dtype=torch.int32)
             self._bounds.zero_()          # one memset per forward; slots are handed out in program order
             self._bound_next = 0
         i = 2

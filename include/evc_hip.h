@@ -222,6 +222,15 @@ int evc_elic_scatter_symbols_f32(const int* symbols, const float* means, float* 
 int evc_elic_quantize_f32(const float* y, int ld, int c0, const float* means, int C, int B, int H, int W,
                           int parity, int* symbols, void* stream);
 
+/* ---- GDN (not on the decode path: g_s / g_a contain none) ---------------------------------
+ * y = x * rsqrt(beta + gamma . x^2) (inverse: * sqrt) -- GDN.forward, ELICUtilis/layers/gdn.py:62-77; simplified != 0:
+ * y = x / (beta + gamma . |x|) -- GDN1.forward, :95-106.  x, out: NHWC with C % 16 == 0; gamma_packed = the
+ * re-parametrised (C, C) gamma packed as a 1x1 convolution weight by evc_conv_pack_weights (EVC_ARITH_F32 or _BF16X6);
+ * beta: the re-parametrised (C,) vector; ws: evc_gdn_workspace_bytes() bytes. */
+long long evc_gdn_workspace_bytes(int B, int H, int W, int C);
+int evc_gdn_f32(const float* x, const void* gamma_packed, int arith, const float* beta, float* out, float* ws, int B,
+                int H, int W, int C, int inverse, int simplified, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

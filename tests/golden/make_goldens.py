@@ -223,6 +223,44 @@ def gen_traj_full():
          stats=torch.stack([o.mean(), o.std(), o.abs().max()]))
 
 
+def gen_unet_ddpm():
+    """The reference's alternative score network models/unet.py::UNet_DDPM (reduced: ngf 32, 32x32), with and without
+    time conditioning, through its own forward and through the reference DDPM sampler."""
+    from models.unet import UNet_DDPM
+    from models import ddpm_sampler
+    from oracle import unet_ddpm as OU
+    out = {}
+    for tc in (True, False):
+        cfg = ref_config(32, 32, 32)
+        cfg.model.time_conditional = tc
+        net = UNet_DDPM(cfg).eval()
+        d = OU.Dims(ngf=32, time_conditional=tc)
+        p = OU.seeded_params(d, 61)
+        own = {k: v for k, v in net.state_dict().items() if k.startswith("unet.")}
+        assert set(own) == set(p), sorted(set(own) ^ set(p))[:8]
+        for k, v in p.items():
+            assert tuple(own[k].shape) == tuple(v.shape), k
+        missing, unexpected = net.load_state_dict(p, strict=False)
+        assert not unexpected and all(not m.startswith("unet.") for m in missing), missing
+        x, cond = rnd(62, 2, 15, 32, 32), rnd(63, 2, 6, 32, 32)
+        tag = "tc" if tc else "notc"
+        with torch.no_grad():
+            out[f"out_{tag}_t0"] = net(x, torch.tensor([0, 0]), cond=cond)
+            out[f"out_{tag}_t500"] = net(x, torch.tensor([500, 500]), cond=cond)
+        if tc:
+            noises = [rnd(70 + i, 2, 15, 32, 32) for i in range(4)]
+            it = iter(noises)
+            orig = torch.randn_like
+            torch.randn_like = lambda t, **kw: next(it)
+            try:
+                out["ddpm_tc"] = ddpm_sampler(x.clone(), net, cond=cond, subsample_steps=4, denoise=True, clip_before=True,
+                                              final_only=True, t_min=-1, log=True)
+            finally:
+                torch.randn_like = orig
+            out["alphas"] = net.alphas
+    save("unet_ddpm", **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -230,7 +268,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     gens = dict(schedule=gen_schedule, fir=gen_fir, blocks=gen_blocks, forward_reduced=gen_forward_reduced,
                 samplers=gen_samplers, forward_full=gen_forward_full, forward_full_b9=gen_forward_full_b9,
-                traj_full=gen_traj_full)
+                traj_full=gen_traj_full, unet_ddpm=gen_unet_ddpm)
     for name, fn in gens.items():
         if a.only and name != a.only:
             continue

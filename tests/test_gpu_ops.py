@@ -403,6 +403,30 @@ def test_attention_key_split_matches_single_pass(L):
     assert lib.evc_attention_ws_f32(*args, L.fptr(out_ws), C, B, heads, N, D, D ** -0.5, None, L.stream_ptr()) == -1
 
 
+@pytest.mark.parametrize("inverse,simplified", [(False, False), (True, False), (False, True), (True, True)])
+def test_gdn_against_formula(L, inverse, simplified):
+    """GDN / IGDN / GDN1 (ELICUtilis/layers/gdn.py:62-77, 95-106) against the formula in fp64, with compressai's
+    NonNegativeParametrizer applied to raw parameters (some below the lower bound, to exercise the clamp)."""
+    B, H, W, C = 2, 12, 10, 192
+    x = rnd(90, B, C, H, W)
+    beta_raw = (1.0 + 0.3 * rnd(91, C)).abs()
+    beta_raw[:5] = 1e-5                                    # below sqrt(beta_min + pedestal): clamped
+    gamma_raw = (0.1 * torch.eye(C) + 0.02 * rnd(92, C, C)).abs().sqrt()
+    gamma_raw[0, :7] = 0.0                                 # below the bound: re-parametrises to exactly 0
+    ped = (2.0 ** -18) ** 2
+    beta = torch.clamp(beta_raw.double(), min=(1e-6 + ped) ** 0.5) ** 2 - ped
+    gamma = torch.clamp(gamma_raw.double(), min=ped ** 0.5) ** 2 - ped
+    xin = x.double().abs() if simplified else x.double() ** 2
+    norm = F.conv2d(xin, gamma.reshape(C, C, 1, 1), beta)
+    if simplified:
+        ref = x.double() * (norm if inverse else 1.0 / norm)
+    else:
+        ref = x.double() * (torch.sqrt(norm) if inverse else torch.rsqrt(norm))
+    op = L.GDN(beta_raw, gamma_raw, inverse=inverse, simplified=simplified)
+    out = op(nhwc(x).cuda())
+    assert rel(nchw(out), ref.float()) < 2e-6
+
+
 def test_layout_pack_and_unpack(L):
     B, H, W = 2, 6, 10
     x, c = rnd(50, B, 15, H, W).cuda(), rnd(51, B, 6, H, W).cuda()

@@ -187,3 +187,29 @@ def test_graph_replay_equals_eager_launches():
     net.use_graphs = True
     assert torch.equal(net.forward_label(x2, 500, cond), ref)
     assert len(net._graphs) == 1      # one (stream, shape) -> one graph, reused for every label and input
+
+
+def test_alt_model_unet_ddpm_against_reference_goldens():
+    """SURVEY.md 8f item 4 -- the reference's other score network, models/unet.py::UNet_DDPM, behind the same sampler API:
+    forward with / without time conditioning at two labels, a mixed-label batch, and a 4-step DDPM trajectory, against
+    outputs of the imported reference (tests/golden/make_goldens.py::gen_unet_ddpm)."""
+    import evc_amd  # noqa: F401
+    from evc_amd import sampler
+    from evc_amd.unet_ddpm import UNetDDPM
+    from oracle import unet_ddpm as OU
+    g = golden("unet_ddpm")
+    x, cond = rnd(62, 2, 15, 32, 32).cuda(), rnd(63, 2, 6, 32, 32).cuda()
+    for tc, tag in ((True, "tc"), (False, "notc")):
+        cfg = make_config(32, 32, 32)
+        cfg.model.time_conditional = tc
+        net = UNetDDPM(cfg, OU.seeded_params(OU.Dims(ngf=32, time_conditional=tc), 61))
+        for lab in (0, 500):
+            assert rel(net(x, torch.tensor([lab, lab]), cond=cond), g[f"out_{tag}_t{lab}"]) < 1e-4, (tag, lab)
+        if tc:
+            mixed = net(x, torch.tensor([0, 500]), cond=cond)           # per-sample labels: one launch per distinct label
+            assert rel(mixed[0], g["out_tc_t0"][0]) < 1e-4 and rel(mixed[1], g["out_tc_t500"][1]) < 1e-4
+            np.testing.assert_array_equal(net.alphas.numpy(), g["alphas"])
+            noises = [rnd(70 + i, 2, 15, 32, 32) for i in range(4)]
+            out = sampler.ddpm_sampler(x, net, cond=cond, subsample_steps=4, denoise=True, clip_before=True,
+                                       final_only=True, noise_fn=lambda i, xx: noises[i])
+            assert out.shape == g["ddpm_tc"].shape and rel(out, g["ddpm_tc"]) < 5e-4

@@ -128,3 +128,26 @@ def test_forward_full_size():
     o = scorenet.forward(p, d, x, torch.tensor([500]), cond=cond)
     assert _rel(o.reshape(-1)[::60].numpy(), g["samples"]) < 5e-5
     assert _rel(o[0, :, 0, :].numpy(), g["first_row"]) < 5e-5
+
+
+def test_unet_ddpm_oracle_matches_reference_goldens():
+    """The alternative score network (reference models/unet.py::UNet_DDPM): oracle forward with and without time
+    conditioning, and a 4-step DDPM trajectory through the oracle sampler, against outputs of the imported reference."""
+    from oracle import samplers as OS, schedule as OSch, unet_ddpm as OU
+    g = golden("unet_ddpm")
+    x, cond = rnd(62, 2, 15, 32, 32), rnd(63, 2, 6, 32, 32)
+    for tc, tag in ((True, "tc"), (False, "notc")):
+        d = OU.Dims(ngf=32, time_conditional=tc)
+        p = OU.seeded_params(d, 61)
+        for lab in (0, 500):
+            out = OU.forward(p, d, x, torch.tensor([lab, lab]), cond=cond)
+            ref = g[f"out_{tag}_t{lab}"]
+            assert float(np.abs(out.numpy() - ref).max() / np.abs(ref).max()) < 2e-5, (tag, lab)
+    assert not np.array_equal(g["out_tc_t0"], g["out_tc_t500"])          # the label matters only when conditional
+    assert np.array_equal(g["out_notc_t0"], g["out_notc_t500"])
+    d = OU.Dims(ngf=32, time_conditional=True)
+    p = OU.seeded_params(d, 61)
+    noises = [rnd(70 + i, 2, 15, 32, 32) for i in range(4)]
+    traj = OS.ddpm(x.clone(), lambda xx, t: OU.forward(p, d, xx, t, cond=cond), OSch.base_schedule(), subsample_steps=4,
+                   noise_fn=lambda i, xx: noises[i])
+    assert float(np.abs(traj.numpy() - g["ddpm_tc"]).max() / np.abs(g["ddpm_tc"]).max()) < 1e-4
