@@ -99,7 +99,7 @@ def main(argv=None):
     from . import ckpt, config as C, lib as L, sampler as S, synthetic
     from .decoder import ClipDecoder
     from .elic import ElicModel, inference
-    from .scorenet import ScoreNet
+    from .scorenet import build_score_network
 
     cfg, raw = C.load_config(args.config, args.config_mod)
     if args.subsample is not None:
@@ -138,7 +138,7 @@ def main(argv=None):
             else:
                 sys.exit(f"missing {pth} (pass --synthetic)")
     sd_d = D.broadcast_state_dict(sd_d, 0, device, world)
-    net = ScoreNet(cfg, sd_d, device=device)
+    net = build_score_network(cfg, sd_d, device=device)     # model.arch: unetmore (default) | unet
     models = {q: ElicModel(D.broadcast_state_dict(sd_e.get(q), 0, device, world), device=device) for q in args.q}
 
     if os.path.exists(args.data_npy):

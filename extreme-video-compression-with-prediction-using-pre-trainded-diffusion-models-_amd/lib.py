@@ -98,6 +98,7 @@ HIP_SYMBOLS = {
     "evc_conv_pack_weights_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "evc_conv_packed_bytes": (c_longlong, [c_int, c_int, c_int, c_int, c_int]),
     "evc_conv_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "evc_conv_set_option": (c_int, [c_char_p, c_int]),
     "evc_conv_choose_splits": (c_int, [POINTER(ConvArgs)]),
     "evc_conv_stats_splits": (c_int, [POINTER(ConvArgs)]),
     "evc_conv_workspace_bytes": (c_longlong, [POINTER(ConvArgs)]),
@@ -343,6 +344,11 @@ def conv_pack_weights(w, arith=None):
     packed = torch.empty((nbytes // dt.itemsize,), device=w.device, dtype=dt)
     _check(L.evc_conv_pack_weights(fptr(w), ptr(packed), Co, Ci, KH, KW, arith, stream_ptr()), "evc_conv_pack_weights")
     return packed
+
+
+def conv_set_option(name, value):
+    """Dispatch switches of the convolution ("tiles2d", "wide_tiles", "row_reuse"): include/evc_hip.h."""
+    _check(hip_lib(require_device=False).evc_conv_set_option(name.encode(), int(value)), "evc_conv_set_option")
 
 
 def packed_arith(w_packed):

@@ -440,3 +440,13 @@ class ScoreNet:
 
     def eval(self):
         return self
+
+
+def build_score_network(config, state_dict, device="cuda", **kw):
+    """``config.model.arch``: "unetmore" -> ScoreNet (the network the reference CLI hard-codes, city_sender.py:311-312);
+    "unet" -> UNetDDPM (reference models/unet.py, upstream MCVD's name for it).  Both plug into the same samplers."""
+    arch = getattr(config.model, "arch", "unetmore")
+    if arch == "unet":
+        from .unet_ddpm import UNetDDPM
+        return UNetDDPM(config, state_dict, device=device)
+    return ScoreNet(config, state_dict, device=device, **kw)

@@ -152,6 +152,10 @@ int evc_conv_pack_weights_f32(const float* w, float* packed, int Co, int Ci, int
  * accumulator scale, weight scale) + [KH*KW][Ci/16][2 planes][CoPad][16 fp16] (4 bytes per element). */
 long long evc_conv_packed_bytes(int Co, int Ci, int KH, int KW, int arith);
 int evc_conv_pack_weights(const float* w, void* packed, int Co, int Ci, int KH, int KW, int arith, void* stream);
+/* Process-wide tuning switches of the convolution dispatch (A/B measurements, tests of non-default kernels; results are
+ * the same up to fp32 summation order): "tiles2d" (default 0: 2-D patch tiles for 3x3 filters), "wide_tiles" (default 1:
+ * 256-pixel row tiles on large unsplit grids), "row_reuse" (default 1).  Returns EVC_EINVAL for an unknown name. */
+int evc_conv_set_option(const char* name, int value);
 int evc_conv_choose_splits(const evc_conv_args* a);
 /* The number of pixel runs per image (H*W/64 or H*W/32) for which the fused moments will be written, when they are
  * available for these arguments (H*W % 64 == 0 and either split-K -- the combine kernel writes them -- or only full

@@ -151,6 +151,37 @@ def test_conv3x3_row_reuse_shapes(L, split_arith, B, H, W, C0, C1, Co, splits):
     assert rel(nchw(out2), ref2) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,C0,C1,Co,splits", [(2, 32, 32, 32, 16, 192, 0), (1, 64, 64, 16, 0, 128, 2), (1, 128, 128, 16, 16, 64, 0),
+                                                    (3, 16, 16, 48, 0, 192, 3), (2, 8, 32, 16, 0, 192, 0)])
+def test_conv3x3_2d_patch_tiles(L, split_arith, B, H, W, C0, C1, Co, splits):
+    """The 2-D patch form of the 3x3 convolution (conv_split_2d_kernel, option "tiles2d": off by default because it
+    measured slower): 32x4 and 16x8 patches, image borders on all four sides, concat sources, GroupNorm+SiLU on load,
+    residual, fused moments, split-K -- same checks as the row-tile kernel."""
+    x0 = rnd(50, B, C0, H, W).cuda()
+    x1 = rnd(51, B, C1, H, W).cuda() if C1 else None
+    C = C0 + C1
+    a, s = (1 + 0.2 * rnd(52, B, C)).cuda(), (0.3 * rnd(53, B, C)).cuda()
+    w = (rnd(54, Co, C, 3, 3) / np.sqrt(9 * C)).cuda()
+    b, res = rnd(55, Co).cuda(), rnd(56, B, Co, H, W).cuda()
+    xin = torch.cat([x0, x1], 1).cpu() if C1 else x0.cpu()
+    ref = (F.conv2d(silu_affine(xin, a.cpu(), s.cpu()), w.cpu(), b.cpu(), padding=1) + res.cpu()) * 0.5
+    wp = L.conv_pack_weights(w, split_arith)
+    L.conv_set_option("tiles2d", 1)
+    try:
+        out, st = L.conv2d_nhwc(nhwc(x0), wp, Co, 3, 3, bias=b, src1=None if x1 is None else nhwc(x1), coef=(a, s),
+                                act_in=L.ACT_SILU, res=nhwc(res), out_scale=0.5, splits=splits, want_stats=True)
+    finally:
+        L.conv_set_option("tiles2d", 0)
+    assert rel(nchw(out), ref) < 1e-5
+    o = out.double().reshape(B, H * W, Co)
+    assert rel(st.double().sum(1).float(), torch.stack([o.sum(1), (o * o).sum(1)], -1).float()) < 1e-5
+    rows = L.conv2d_nhwc(nhwc(x0), wp, Co, 3, 3, bias=b, src1=None if x1 is None else nhwc(x1), coef=(a, s),
+                         act_in=L.ACT_SILU, res=nhwc(res), out_scale=0.5, splits=splits)
+    assert rel(out, rows) < 2e-6                              # row tiles: same values up to summation order
+    with pytest.raises(L.EvcKernelError):
+        L.conv_set_option("no_such_option", 1)
+
+
 def test_conv_bf16x6_is_not_less_accurate_than_f32_mfma(L):
     """The precision claim of EVC_ARITH_BF16X6 and EVC_ARITH_F16X3, on the real kernels: against an fp64 reference
     their error is no larger than that of the exact-product f32 MFMA path (all accumulate in fp32), for the dominant

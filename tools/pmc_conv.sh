@@ -14,7 +14,7 @@ for set in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" \
            "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
   echo "pass $i: $set"
-  timeout -k 5 120 rocprofv3 --kernel-trace --pmc $set -d "$OUT/p$i" -o pass --output-format csv -- ./tools/conv_bench_split 5 3 "$SHAPE" > "$OUT/p$i.log" 2>&1 || echo "pass $i failed"
+  timeout -k 5 120 rocprofv3 --kernel-trace --pmc $set -d "$OUT/p$i" -o pass --output-format csv -- ./tools/conv_bench_split ${LAYOUT:-5} 3 "$SHAPE" > "$OUT/p$i.log" 2>&1 || echo "pass $i failed"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
@@ -24,7 +24,8 @@ dur = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        name = ("rr_bf16x6" if "conv_split_rr_kernel<3" in k else "rr_f16x3" if "conv_split_rr_kernel<2" in k else
+        name = ("2d_bf16x6" if "conv_split_2d_kernel<3" in k else "2d_f16x3" if "conv_split_2d_kernel<2" in k else
+                "rr_bf16x6" if "conv_split_rr_kernel<3" in k else "rr_f16x3" if "conv_split_rr_kernel<2" in k else
                 "sn_f16x3" if "conv_splitn_kernel" in k else "split_bf16x6" if "conv_split_kernel" in k else
                 "f32" if "conv_igemm_kernel" in k else None)
         if not name: continue
