@@ -384,9 +384,10 @@ def main():
     flop_per_step_gpu = a.clips * (6 * fwd_per_chunk * FWD_FLOP_PER_SAMPLE + 2 * ELIC_DECODE_FLOP)
     policy = {L.ARITH_F32: "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere",
               L.ARITH_BF16X6: "conv products as 6 bf16 MFMAs on an exact 3-way bf16 split of both operands",
-              L.ARITH_F16X3: "convs on normalised inputs (Conv_0/Conv_1/qkv/output conv: 94 % of the FLOPs): operands scaled "
-                             "into fp16 range, 2-way fp16 split, 3 fp16 MFMAs per product; raw residual-stream convs, NIN out "
-                             "projections, ELIC: exact 3-way bf16 split, 6 bf16 MFMAs"}[L.bounded_arith()]
+              L.ARITH_F16X3: "score-network convolutions and attention: operands scaled by powers of two into fp16 range "
+                             "(GroupNorm-ed inputs by 8, raw inputs by a bound from their moments, weights per tensor), 2-way "
+                             "fp16 split (22 significand bits), 3 fp16 MFMAs per product; input conv, AdaGN tables, ELIC: exact "
+                             "3-way bf16 split, 6 bf16 MFMAs"}[L.bounded_arith()]
     out = {"metric": "decoded frames/sec (128x128x30) at q3", "value": round(value, 4), "unit": "frames/s",
            "n_gpus": world, "ranks_seen": seen, "backend": D.backend_name(),
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),

@@ -47,6 +47,32 @@ def test_cli_end_to_end_synthetic(tmp_path, monkeypatch):
     assert np.load(d / "psnr_0.npy").shape[0] == 2
 
 
+def test_cli_quality_sweep_q0_to_q5(tmp_path, monkeypatch):
+    """BASELINE.json configs[3] -- the quality sweep q0..q5 through the CLI (`--q 0 1 2 3 4 5`; the reference hard-codes
+    q4, q5: city_sender.py:504): one ELIC model per quality index, per-q outputs under the reference's file names, one
+    rate point per q in bpp_<idx>.npy and the RD envelope in psnr_<idx>.npy.  Seeded stand-in weights (the real
+    checkpoints are not available offline), so only the plumbing is asserted, not the shape of the curve."""
+    import evc_amd  # noqa: F401
+    from evc_amd import cli
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.chdir(tmp_path)
+    out = tmp_path / "out"
+    cli.main(["--config", os.path.join(repo, "configs", "mine.yml"), "--synthetic", "--exp", str(tmp_path / "exp"),
+              "--data_npy", "missing.npy", "--output_path", str(out), "--start_idx", "0", "--end_idx", "1", "--batch", "2",
+              "--subsample", "2", "--q", "0", "1", "2", "3", "4", "5",
+              "--config_mod", "model.ngf=32 model.n_head_channels=32"])
+    for vid in (0, 1):
+        d = out / f"output_{vid}"
+        for q in range(6):
+            assert os.path.exists(d / ("city_output_npy_idx%d_q%d_thr0.00.npy" % (vid, q)))
+        bpp = np.load(d / f"bpp_{vid}.npy")
+        ps = np.load(d / f"psnr_frames_{vid}.npy")
+        assert bpp.shape == (6,) and (bpp > 0).all() and ps.shape == (6, 30) and np.isfinite(ps).all()
+        assert len(set(np.round(bpp, 9))) > 1                     # different codecs -> different rates
+        env = np.load(d / f"psnr_{vid}.npy")
+        assert env.shape[0] == 2 and 1 <= env.shape[1] <= 6 and set(np.round(env[0], 9)) <= set(np.round(bpp, 9))
+
+
 def test_batched_policy_sweep_equals_one_job_at_a_time():
     """policy.run_policy advances every (video, q, threshold) job in lockstep, stacked along the batch axis; with
     per-job noise streams the accept / fall-back decisions (the transmit masks d) and the bit counts equal those of a
