@@ -73,6 +73,7 @@ struct CoefArgs {
 // block (fixed assignment + fixed tree => deterministic), then the group's channels get their coefficients.
 __global__ __launch_bounds__(256) void gn_coeffs_kernel(CoefArgs a) {
     __shared__ double red[2][4];
+    __shared__ float redmx[4];
     const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int C = a.C0 + a.C1;
     const int cpg = C / a.groups;
@@ -101,10 +102,15 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(CoefArgs a) {
         sq += __shfl_xor(sq, off);
         mx = fmaxf(mx, __shfl_xor(mx, off));
     }
-    // max is order-independent, so the atomic keeps the result deterministic; non-negative floats order like their bits
-    if (a.bound_bits && (tid & 63) == 0 && mx > 0.f) atomicMax(a.bound_bits, __float_as_uint(mx));
-    if ((tid & 63) == 0) { red[0][tid >> 6] = sm; red[1][tid >> 6] = sq; }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = sm; red[1][tid >> 6] = sq; redmx[tid >> 6] = mx; }
     __syncthreads();
+    // max is order-independent, so the atomic keeps the result deterministic; non-negative floats order like their bits.
+    // One atomic per block, and none when the word already holds a larger value (it only ever grows): 288 blocks hitting
+    // one address cost the launch 2-3 us otherwise.
+    if (a.bound_bits && tid == 0) {
+        const unsigned bits = __float_as_uint(fmaxf(fmaxf(redmx[0], redmx[1]), fmaxf(redmx[2], redmx[3])));
+        if (bits > __hip_atomic_load(a.bound_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.bound_bits, bits);
+    }
     sm = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     sq = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     const double n = (double)cpg * (double)a.HW;
@@ -137,7 +143,13 @@ __global__ __launch_bounds__(256) void moments_bound_kernel(const float* __restr
     for (int i = threadIdx.x; i < c_count; i += 256) mx = fmaxf(mx, row[2 * i + 1]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(bound_bits, __float_as_uint(mx));
+    __shared__ float redmx[4];
+    if ((threadIdx.x & 63) == 0) redmx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned bits = __float_as_uint(fmaxf(fmaxf(redmx[0], redmx[1]), fmaxf(redmx[2], redmx[3])));
+        if (bits > __hip_atomic_load(bound_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(bound_bits, bits);
+    }
 }
 
 __device__ __forceinline__ float act_fn(float v, int act) {
