@@ -94,6 +94,10 @@ def roofline_leg(net, clips, device):
     from evc_amd import lib as L
     x = torch.randn(clips, 15, 128, 128, device=device)
     c = torch.randn(clips, 6, 128, 128, device=device)
+    # per-kernel durations: the forward normally overlaps each res-block's 1x1 skip convolution (side stream) with its
+    # 3x3 convolution; HIP events around concurrent launches would charge each with the other's time, so the profiled
+    # forwards run the launches one after another on one stream
+    overlap, net.overlap_skip = getattr(net, "overlap_skip", False), False
     net.forward_label(x, 500, c)            # warm
     torch.cuda.synchronize()
     prof = []
@@ -103,6 +107,7 @@ def roofline_leg(net, clips, device):
         net.forward_label(x, 500, c)
     L.CONV_PROFILE = None
     torch.cuda.synchronize()
+    net.overlap_skip = overlap
     per = {}
     for r in prof:
         v = per.setdefault((r["arith"], r["variant"]), dict(n=0, ms=0.0, flops=0.0))

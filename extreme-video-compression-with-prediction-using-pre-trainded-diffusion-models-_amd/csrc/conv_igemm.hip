@@ -75,6 +75,12 @@ typedef const __attribute__((address_space(1))) void glb_void;
                                // (f16x3 128x128 192->192: 290 vs 316 TFLOP/s; same MFMA count, +21 % issue-stall cycles, and its
                                // per-pixel epilogue addressing costs what the staging saves) -- off; kept selectable + tested.
 #endif
+#ifndef EVC_2D_FRAG_BARRIER
+#define EVC_2D_FRAG_BARRIER 1
+#endif
+#ifndef EVC_2D_STAGE_MID
+#define EVC_2D_STAGE_MID 0
+#endif
 #ifndef EVC_RR_BALANCE
 #define EVC_RR_BALANCE 0       // row-reuse kernel: 1 = the staging arithmetic of the next activation image is spread over two
                                // K-steps (transform during tx = 1, split + LDS write during tx = 2); 0 = all of it in tx = 2.
@@ -1333,6 +1339,9 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
     #undef EVC_RR_NEXT_W
     }
 
+#if EVC_CONV_ABLATE & 16      // diagnostic: no epilogue at run time (the accumulators stay live for the compiler)
+    if (p.M > 0) return;
+#endif
     conv_epilogue<TM, TN, WM>(p, acc, m0, n0, split, wm, wn, l31, half);
 }
 
@@ -1519,17 +1528,31 @@ __global__ __launch_bounds__(256, 2) void conv_split_2d_kernel(ConvK p, int ltw)
                 }
                 // all ten fragment reads in flight before the first MFMA (left alone, the scheduler re-uses fragment
                 // registers and serialises read -> wait -> 3 MFMAs four times per K-step)
+#if EVC_2D_FRAG_BARRIER
                 __builtin_amdgcn_sched_barrier(0);
+#endif
+                // staging of the next chunk's patch: unit 0 in the K-step of tap 4, unit 1 in that of tap 7 (the loads were
+                // issued at tap 0 and drained by the barriers of taps 1..); EVC_2D_STAGE_MID: between the MFMA halves
+                const bool st0 = ty == 1 && tx == 1, st1 = ty == 2 && tx == 1;
 #pragma unroll
-                for (int t = 0; t < SP::NTERM; ++t)
+                for (int t = 0; t < SP::NTERM; ++t) {
+#if EVC_2D_STAGE_MID
+                    if (t == (SP::NTERM + 1) / 2 && tx == 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (st0) store_unit(0, ab ^ 1);
+                        if (st1) store_unit(1, ab ^ 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j) acc[i][j] = SP::mfma(a[i][SP::qa(t)], bq[j][SP::qb(t)], acc[i][j]);
-                // staging of the next chunk's patch: unit 0 behind the MFMAs of tap 4, unit 1 behind tap 7 (the loads were
-                // issued at tap 0 and drained by the barriers of taps 1..)
-                if (ty == 1 && tx == 1) { __builtin_amdgcn_sched_barrier(0); store_unit(0, ab ^ 1); }
-                if (ty == 2 && tx == 1) { __builtin_amdgcn_sched_barrier(0); store_unit(1, ab ^ 1); }
+                }
+#if !EVC_2D_STAGE_MID
+                if (st0) { __builtin_amdgcn_sched_barrier(0); store_unit(0, ab ^ 1); }
+                if (st1) { __builtin_amdgcn_sched_barrier(0); store_unit(1, ab ^ 1); }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (ty == 0 && tx == 0) {   // weight DMA landed; the coefficient + activation loads (the youngest) stay in flight
                     if constexpr (HAS_COEF) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");

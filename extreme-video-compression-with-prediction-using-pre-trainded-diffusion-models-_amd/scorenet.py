@@ -145,6 +145,10 @@ class ScoreNet:
         self._graphs = {}
         # fp16-split convolutions on raw (un-normalised) inputs take an element bound from the tensors' moments
         self._f16_raw = L.bounded_arith() == L.ARITH_F16X3
+        # the x-branch of a res-block (1x1 skip convolution) on a side stream, overlapped with the h-branch
+        import os
+        self.overlap_skip = os.environ.get("EVC_OVERLAP_SKIP", "1") != "0"
+        self._side_streams = {}
         self._bounds_by_stream = {}      # concurrent clip groups run forwards on their own streams: one arena each
         self._bounds = None
         self._bound_next = 0
@@ -259,6 +263,14 @@ class ScoreNet:
         return L.gn_coeffs(parts, hw, num_groups(ch), 1e-5, mode=2, ss=self._table[:, off:off + 2 * c], row=rows,
                            bound=bound)
 
+    def _side_stream(self, main):
+        """The side stream paired with a main stream (one per concurrent clip group / capture)."""
+        key = main.cuda_stream
+        st = self._side_streams.get(key)
+        if st is None:
+            st = self._side_streams[key] = torch.cuda.Stream(device=self.device)
+        return st
+
     def _bound_slot(self, n=1):
         """n zeroed device words of this forward's arena (element bounds for the fp16-split kernels on raw inputs)."""
         if not self._f16_raw:
@@ -274,15 +286,38 @@ class ScoreNet:
         parts = [x.stats()] + ([skip.stats()] if skip is not None else [])
         xbound = self._bound_slot() if "w2" in e else None     # bounds x (and skip): also FIR(x), whose taps sum to 1
         coef0 = self._adagn(parts, H * W, m["cin"], e["ss0"], rows, bound=xbound)
+        fir = None
         if m["up"] or m["down"]:
-            if m["up"]:
-                k, up, down, pad = FIR_K * 4.0, 2, 1, (2, 1)     # upsample_2d: gain factor**2, pad (2, 1)
-            else:
-                k, up, down, pad = FIR_K, 1, 2, (1, 1)           # downsample_2d: pad (1, 1)
-            hf = L.upfirdn2d_nhwc(x.t, k, up, down, pad, coef=coef0, act=L.ACT_SILU)
-            xf = L.upfirdn2d_nhwc(x.t, k, up, down, pad)
+            fir = (FIR_K * 4.0, 2, 1, (2, 1)) if m["up"] else (FIR_K, 1, 2, (1, 1))   # upsample_2d: gain factor**2, pad (2, 1)
+                                                                                      # downsample_2d: pad (1, 1)
+        s1 = None if skip is None else skip.t
+
+        def skip_path(out):
+            """x-branch of the block: [FIR ->] 1x1 skip convolution (models/better/layerspp.py:603-614)."""
+            src, src1 = x.t, s1
+            if fir is not None:
+                src, src1 = L.upfirdn2d_nhwc(x.t, *fir), None
+            if "w2" in e:
+                return L.conv2d_nhwc(src, e["w2"], m["cout"], 1, 1, bias=e["b2"], src1=src1, in_bound=xbound, out=out)
+            return src
+
+        # The x-branch only depends on the block input: with `overlap_skip` it runs on a side stream while the main stream
+        # does the h-branch (FIR, Conv_0, its moments), so its small latency-bound launches (the 1x1 convolution, its
+        # split-K combine) hide behind Conv_0 instead of sitting in front of Conv_1.  Joined by an event before Conv_1.
+        side = done = xs = None
+        if self.overlap_skip and "w2" in e:
+            main = torch.cuda.current_stream()
+            side = self._side_stream(main)
+            Ho, Wo = (2 * H, 2 * W) if m["up"] else ((H // 2, W // 2) if m["down"] else (H, W))
+            xs = torch.empty((B, Ho, Wo, m["cout"]), device=self.device, dtype=torch.float32)   # owned by the main stream
+            side.wait_stream(main)                # coef0's launch raised the bound word; x / skip are complete
+            with torch.cuda.stream(side):
+                skip_path(xs)
+                done = torch.cuda.Event()
+                done.record(side)
+        if fir is not None:
+            hf = L.upfirdn2d_nhwc(x.t, *fir, coef=coef0, act=L.ACT_SILU)
             h1 = _Act(*L.conv2d_nhwc(hf, e["w0"], m["cout"], 3, 3, bias=e["b0"], want_stats=True))
-            xs_src, xs_skip = xf, None
         elif self.preactivate:
             cin = m["cin"]
             act = torch.empty((B, H, W, cin), device=self.device, dtype=torch.float32)
@@ -291,18 +326,15 @@ class ScoreNet:
             if skip is not None:
                 L.affine_act(skip.t, coef0, L.ACT_SILU, out=L.Cols(act, c0, cin - c0), coef_col=c0)
             h1 = _Act(*L.conv2d_nhwc(act, e["w0"], m["cout"], 3, 3, bias=e["b0"], want_stats=True))
-            xs_src, xs_skip = x.t, (None if skip is None else skip.t)
         else:
-            h1 = _Act(*L.conv2d_nhwc(x.t, e["w0"], m["cout"], 3, 3, bias=e["b0"],
-                                     src1=None if skip is None else skip.t, coef=coef0, act_in=L.ACT_SILU,
+            h1 = _Act(*L.conv2d_nhwc(x.t, e["w0"], m["cout"], 3, 3, bias=e["b0"], src1=s1, coef=coef0, act_in=L.ACT_SILU,
                                      want_stats=True))
-            xs_src, xs_skip = x.t, (None if skip is None else skip.t)
         H1, W1 = h1.t.shape[1], h1.t.shape[2]
         coef1 = self._adagn([h1.stats()], H1 * W1, m["cout"], e["ss1"], rows)
-        if "w2" in e:
-            xs = L.conv2d_nhwc(xs_src, e["w2"], m["cout"], 1, 1, bias=e["b2"], src1=xs_skip, in_bound=xbound)
+        if side is None:
+            xs = skip_path(None)
         else:
-            xs = xs_src
+            torch.cuda.current_stream().wait_event(done)
         if self.preactivate:
             h1a = L.affine_act(h1.t, coef1, L.ACT_SILU)
             return _Act(*L.conv2d_nhwc(h1a, e["w1"], m["cout"], 3, 3, bias=e["b1"], res=xs, out_scale=INV_SQRT2,
