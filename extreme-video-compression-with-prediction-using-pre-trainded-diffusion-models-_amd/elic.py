@@ -7,9 +7,9 @@ Host-side mirror of the reference's ``TestModel`` (Network.py:74-640) and ``Infe
 
 Every convolution runs through ``evc_conv2d_nhwc_f32`` (NHWC, f32 matrix cores):
 * ReLUs are folded into the consumer's operand load / the producer's epilogue;
-* the 5x5 stride-2 transposed convolutions (compressai ``deconv``) = zero insertion
-  (``evc_upfirdn2d_nhwc_f32`` with a 1x1 kernel, up 2) + 5x5 "same" convolution with the flipped,
-  transposed kernel; the 5x5 stride-2 convolutions of the encoder = "same" convolution + decimation;
+* the 5x5 stride-2 transposed / strided convolutions (compressai ``deconv`` / ``conv``) run in polyphase form
+  (``evc_deconv5x5s2_f32`` / ``evc_conv5x5s2_f32``: one 3x3 convolution on the low-resolution side + a layout pass,
+  36 instead of 100 MACs per pixel and channel pair; exactly the same sums);
 * the checkerboard-masked 5x5 context convolution uses weights masked once at load
   (the reference re-masks on every forward, ELICUtilis/layers/layers.py:85);
 * the concat feeding ParamAggregation is never materialised: context + channel-conditional outputs are
@@ -27,7 +27,7 @@ GROUPS = [0, 16, 16, 32, 64, 192]   # Network.py:87
 ONE = np.ones((1, 1), dtype=np.float32)
 # Bumped whenever a change to the convolution kernels can alter the last bit of the entropy-parameter networks' outputs
 # (summation order, tile shapes ...): streams carry it (container.py) and receivers refuse a mismatch.
-ELIC_CODEC_REV = 2
+ELIC_CODEC_REV = 3
 
 
 def _pad16(c):
@@ -50,8 +50,12 @@ class ElicModel:
                                           "ParamAggregation"):
                 continue
             w = sd[k].detach().float()
-            if self._is_deconv(name):
-                w = w.permute(1, 0, 2, 3).flip(2, 3)          # (in,out,kh,kw) -> conv weight of the stuffed input
+            if self._is_deconv(name):                         # compressai deconv(): polyphase 3x3 form
+                self.w[name] = L.Deconv5x5s2(w, sd[name + ".bias"], self.arith, self.device)
+                continue
+            if self._is_conv_s2(name):                        # compressai conv(): space-to-depth + 3x3
+                self.w[name] = L.Conv5x5s2(w, sd[name + ".bias"], self.arith, self.device)
+                continue
             if name.startswith("context_prediction"):
                 mask = sd.get(name + ".mask")
                 if mask is None:
@@ -80,6 +84,10 @@ class ElicModel:
     def _is_deconv(name):
         return name in ("g_s.1", "g_s.5", "g_s.10", "g_s.14", "h_s.0", "h_s.2")
 
+    @staticmethod
+    def _is_conv_s2(name):
+        return name in ("g_a.0", "g_a.4", "g_a.9", "g_a.13", "h_a.2", "h_a.4")
+
     # ---- layer helpers (all NHWC) --------------------------------------------------------------
     def _conv(self, name, x, src1=None, act_in=L.ACT_NONE, act_out=L.ACT_NONE, res=None, out=None):
         e = self.w[name]
@@ -90,12 +98,11 @@ class ElicModel:
                              act_out=act_out, res=res, out=out, splits=1)
 
     def _deconv(self, name, x, act_out=L.ACT_NONE):
-        z = L.upfirdn2d_nhwc(x, ONE, 2, 1, (0, 0))                # zero insertion -> (2H, 2W)
-        return self._conv(name, z, act_out=act_out)
+        return self.w[name](x, act_out=act_out)                   # (B, H, W, Ci) -> (B, 2H, 2W, Co)
 
     def _conv_s2(self, name, x, act_out=L.ACT_NONE):
-        y = self._conv(name, x, act_out=act_out)                  # stride-1 "same" ...
-        return L.upfirdn2d_nhwc(y, ONE, 1, 2, (0, 0))             # ... then keep every 2nd sample
+        op = self.w[name]
+        return op(x, act_out=act_out, channels=op.Ci)             # (B, 2H, 2W, ld >= Ci) -> (B, H, W, Co)
 
     def _rbb(self, n, x):
         """ResidualBottleneckBlock (Network.py:48-59)."""

@@ -88,6 +88,14 @@ HIP_SYMBOLS = {
     "evc_moments_bound_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "evc_attention_f16x3_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_float, c_void_p, c_void_p, c_void_p]),
+    "evc_deconv5x5s2_phase_weights_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "evc_conv5x5s2_phase_weights_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "evc_depth_to_space2_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "evc_space_to_depth2_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "evc_deconv5x5s2_workspace_bytes": (c_longlong, [c_int, c_int, c_int, c_int]),
+    "evc_deconv5x5s2_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "evc_conv5x5s2_workspace_bytes": (c_longlong, [c_int, c_int, c_int, c_int]),
+    "evc_conv5x5s2_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "evc_gdn_workspace_bytes": (c_longlong, [c_int, c_int, c_int, c_int]),
     "evc_gdn_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                             c_int, c_void_p]),
@@ -474,6 +482,63 @@ def attention(qkv, C, heads, out=None, bounds=None):
     _check(L.evc_attention_ws_f32(c_void_p(base), c_void_p(base + 4 * C), c_void_p(base + 8 * C), ld, fptr(out), C, B,
                                   heads, N, D, float(int(D) ** (-0.5)), ptr(ws), stream_ptr()), "evc_attention_ws_f32")
     return out
+
+
+class Deconv5x5s2:
+    """compressai ``deconv`` (ConvTranspose2d k 5, stride 2, padding 2, output_padding 1) in polyphase form
+    (include/evc_hip.h, csrc/stride2.hip).  ``weight``: the module's (Ci, Co, 5, 5) tensor, ``bias``: (Co,)."""
+
+    def __init__(self, weight, bias, arith=None, device="cuda"):
+        Lh = hip_lib()
+        w = weight.detach().to(device, torch.float32).contiguous()
+        self.Ci, self.Co = w.shape[0], w.shape[1]
+        self.Cp, self.CiPad = (self.Co + 15) // 16 * 16, (self.Ci + 15) // 16 * 16
+        wp = torch.empty((4 * self.Cp, self.CiPad, 3, 3), device=device, dtype=torch.float32)
+        _check(Lh.evc_deconv5x5s2_phase_weights_f32(fptr(w), fptr(wp), self.Ci, self.Co, self.Cp, self.CiPad, stream_ptr()),
+               "evc_deconv5x5s2_phase_weights_f32")
+        self.arith = default_arith() if arith is None else arith
+        self.w = conv_pack_weights(wp, self.arith)
+        b4 = torch.zeros((4, self.Cp), device=device, dtype=torch.float32)
+        b4[:, :self.Co] = bias.detach().to(device, torch.float32)[None, :]
+        self.bias4 = b4.reshape(-1).contiguous()
+
+    def __call__(self, x, act_out=ACT_NONE):
+        B, H, W, C = x.shape
+        assert C == self.CiPad and x.dtype == torch.float32 and x.is_contiguous()
+        Lh = hip_lib()
+        ws = _workspace(Lh.evc_deconv5x5s2_workspace_bytes(B, H, W, self.Cp), x.device)
+        out = torch.empty((B, 2 * H, 2 * W, self.Co), device=x.device, dtype=torch.float32)
+        _check(Lh.evc_deconv5x5s2_f32(fptr(x), ptr(self.w), self.arith, fptr(self.bias4), fptr(out), ptr(ws), B, H, W, C,
+                                      self.Co, act_out, stream_ptr()), "evc_deconv5x5s2_f32")
+        return out
+
+
+class Conv5x5s2:
+    """compressai ``conv`` (Conv2d k 5, stride 2, padding 2) in polyphase form.  ``weight``: (Co, Ci, 5, 5)."""
+
+    def __init__(self, weight, bias, arith=None, device="cuda"):
+        Lh = hip_lib()
+        w = weight.detach().to(device, torch.float32).contiguous()
+        self.Co, self.Ci = w.shape[0], w.shape[1]
+        self.Cq = (self.Ci + 3) // 4 * 4
+        wq = torch.empty((self.Co, 4 * self.Cq, 3, 3), device=device, dtype=torch.float32)
+        _check(Lh.evc_conv5x5s2_phase_weights_f32(fptr(w), fptr(wq), self.Co, self.Ci, self.Cq, stream_ptr()),
+               "evc_conv5x5s2_phase_weights_f32")
+        self.arith = default_arith() if arith is None else arith
+        self.w = conv_pack_weights(wq, self.arith)
+        self.bias = bias.detach().to(device, torch.float32).contiguous()
+
+    def __call__(self, x, act_out=ACT_NONE, channels=None):
+        """x: (B, 2Ho, 2Wo, ld) of which the first ``channels`` (default all) are the input."""
+        B, H2, W2, ld = x.shape
+        C = ld if channels is None else channels
+        assert C == self.Ci and ld >= C and H2 % 2 == 0 and W2 % 2 == 0 and x.is_contiguous()
+        Lh = hip_lib()
+        ws = _workspace(Lh.evc_conv5x5s2_workspace_bytes(B, H2 // 2, W2 // 2, C), x.device)
+        out = torch.empty((B, H2 // 2, W2 // 2, self.Co), device=x.device, dtype=torch.float32)
+        _check(Lh.evc_conv5x5s2_f32(fptr(x), ld, ptr(self.w), self.arith, fptr(self.bias), fptr(out), ptr(ws), B, H2 // 2,
+                                    W2 // 2, C, self.Co, act_out, stream_ptr()), "evc_conv5x5s2_f32")
+        return out
 
 
 class GDN:

@@ -226,6 +226,29 @@ int evc_elic_scatter_symbols_f32(const int* symbols, const float* means, float* 
 int evc_elic_quantize_f32(const float* y, int ld, int c0, const float* means, int C, int B, int H, int W,
                           int parity, int* symbols, void* stream);
 
+/* ---- ELIC stride-2 convolutions, polyphase form (csrc/stride2.hip) ----------------------------------------------
+ * compressai deconv() = ConvTranspose2d(k 5, stride 2, padding 2, output_padding 1) and conv() = Conv2d(k 5, stride 2,
+ * padding 2) (reference Network.py:88-138).  Exactly the same sums as the direct forms, as ONE 3x3 stride-1 convolution
+ * (evc_conv2d_nhwc_f32) on the low-resolution side plus a layout pass: 36 MACs per low-resolution pixel and channel pair
+ * instead of the 100 of zero-insertion / decimation around a 5x5 "same" convolution.
+ *   evc_deconv5x5s2_phase_weights_f32: ConvTranspose2d weight wt [Ci][Co][5][5] -> wp [4*Cp][CiPad][3][3] (phase-major
+ *       output channels, zero taps where a phase has two; Cp >= Co, CiPad >= Ci), to be packed by evc_conv_pack_weights.
+ *   evc_conv5x5s2_phase_weights_f32: Conv2d weight w [Co][Ci][5][5] -> wq [Co][4*Cq][3][3] over the space-to-depth input.
+ *   evc_depth_to_space2_f32 / evc_space_to_depth2_f32: the layout passes (pure permutations, zero padding channels).
+ *   evc_deconv5x5s2_f32: x [B][H][W][Ci] -> out [B][2H][2W][Co]; bias4 [4*Cp] = the bias repeated per phase.
+ *   evc_conv5x5s2_f32:   x [B][2Ho][2Wo][ld_in] (first Ci channels) -> out [B][Ho][Wo][Co]. */
+int evc_deconv5x5s2_phase_weights_f32(const float* wt, float* wp, int Ci, int Co, int Cp, int CiPad, void* stream);
+int evc_conv5x5s2_phase_weights_f32(const float* w, float* wq, int Co, int Ci, int Cq, void* stream);
+int evc_depth_to_space2_f32(const float* in, int ld_in, int Cp, float* out, int C, int B, int H, int W, void* stream);
+int evc_space_to_depth2_f32(const float* in, int ld_in, int C, float* out, int ld_out, int Cq, int B, int H, int W,
+                            void* stream);
+long long evc_deconv5x5s2_workspace_bytes(int B, int H, int W, int Cp);
+int evc_deconv5x5s2_f32(const float* x, const void* w_packed, int arith, const float* bias4, float* out, float* ws, int B,
+                        int H, int W, int Ci, int Co, int act_out, void* stream);
+long long evc_conv5x5s2_workspace_bytes(int B, int Ho, int Wo, int Ci);
+int evc_conv5x5s2_f32(const float* x, int ld_in, const void* w_packed, int arith, const float* bias, float* out, float* ws,
+                      int B, int Ho, int Wo, int Ci, int Co, int act_out, void* stream);
+
 /* ---- GDN (not on the decode path: g_s / g_a contain none) ---------------------------------
  * y = x * rsqrt(beta + gamma . x^2) (inverse: * sqrt) -- GDN.forward, ELICUtilis/layers/gdn.py:62-77; simplified != 0:
  * y = x / (beta + gamma . |x|) -- GDN1.forward, :95-106.  x, out: NHWC with C % 16 == 0; gamma_packed = the

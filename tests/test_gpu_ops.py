@@ -458,6 +458,37 @@ def test_gdn_against_formula(L, inverse, simplified):
     assert rel(nchw(out), ref.float()) < 2e-6
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 8, 8, 320, 192), (1, 16, 16, 192, 192), (3, 64, 64, 192, 3), (2, 2, 2, 192, 320)])
+def test_deconv5x5s2_polyphase_vs_conv_transpose(L, B, H, W, Ci, Co):
+    """evc_deconv5x5s2_f32 = compressai deconv(): ConvTranspose2d(k 5, stride 2, padding 2, output_padding 1), as one 3x3
+    convolution with 4*Co phase-major outputs + depth-to-space (the g_s / h_s shapes of ELIC, incl. the 192 -> 3 output
+    layer and the 2x2 hyper-latent)."""
+    x = rnd(100, B, Ci, H, W)
+    w = rnd(101, Ci, Co, 5, 5) / np.sqrt(Ci * 25 / 4)
+    b = rnd(102, Co)
+    ref = F.relu(F.conv_transpose2d(x, w, b, stride=2, padding=2, output_padding=1))
+    op = L.Deconv5x5s2(w, b)
+    out = op(nhwc(x).cuda(), act_out=L.ACT_RELU)
+    assert out.shape == (B, 2 * H, 2 * W, Co)
+    assert rel(nchw(out), ref) < 1e-5
+
+
+@pytest.mark.parametrize("B,Ho,Wo,Ci,Co,ld", [(2, 32, 32, 3, 192, 16), (1, 16, 16, 192, 192, 192), (2, 4, 4, 192, 320, 192),
+                                               (3, 1, 1, 192, 192, 192)])
+def test_conv5x5s2_polyphase_vs_strided_conv(L, B, Ho, Wo, Ci, Co, ld):
+    """evc_conv5x5s2_f32 = compressai conv(): Conv2d(k 5, stride 2, padding 2), as space-to-depth + one 3x3 convolution
+    (the g_a / h_a shapes of ELIC, incl. the 3-channel image packed into a 16-wide NHWC row)."""
+    x = rnd(103, B, Ci, 2 * Ho, 2 * Wo)
+    w = rnd(104, Co, Ci, 5, 5) / np.sqrt(Ci * 25)
+    b = rnd(105, Co)
+    ref = F.conv2d(x, w, b, stride=2, padding=2)
+    xin = torch.full((B, 2 * Ho, 2 * Wo, ld), 7.0)                 # padding channels hold junk: they must not be read
+    xin[..., :Ci] = nhwc(x)
+    out = L.Conv5x5s2(w, b)(xin.cuda(), channels=Ci)
+    assert out.shape == (B, Ho, Wo, Co)
+    assert rel(nchw(out), ref) < 1e-5
+
+
 def test_layout_pack_and_unpack(L):
     B, H, W = 2, 6, 10
     x, c = rnd(50, B, 15, H, W).cuda(), rnd(51, B, 6, H, W).cuda()
