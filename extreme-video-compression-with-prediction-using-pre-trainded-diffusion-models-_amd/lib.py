@@ -447,7 +447,11 @@ def conv2d_nhwc(src0, w_packed, Co, KH, KW, bias=None, src1=None, coef=None, act
         e1.record(st)
         CONV_PROFILE.append(dict(variant=conv_variant(Co), split=nbytes > 0, e0=e0, e1=e1, arith=a.arith,
                                  flops=2.0 * B * H * W * Co * KH * KW * (C0 + C1),
-                                 shape=(B, H, W, C0 + C1, Co, KH)))
+                                 shape=(B, H, W, C0 + C1, Co, KH),
+                                 call=dict(B=B, H=H, W=W, C0=C0, C1=C1, Co=Co, K=KH, coef=coef is not None, act_in=act_in,
+                                           res=res is not None, out_scale=float(out_scale), bias=bias is not None,
+                                           bound=in_bound is not None, arith=a.arith, ld_out=ldo,
+                                           stats=bool(want_stats))))
     result = out.t if isinstance(out, Cols) else out
     if want_stats:
         return result, (stats if stats is not None else chan_stats(result))

@@ -85,8 +85,11 @@ def test_generation_is_invariant_to_concurrent_clip_grouping():
 
     def noise_fn(tag, shp):      # pure function of the tag, so every group slices the same tensor
         return rnd(hash(str(tag)) % 1000 + 7, *shp)
-    for name, graphs in (("DDPM", False), ("DDIM", False), ("DDPM", True)):
+    # F-PNDM: its Runge-Kutta midpoint / -1 label rows must be in the AdaGN table before the groups fan out to their
+    # own streams (a row built lazily on one group's stream was read by the others with no ordering)
+    for name, graphs in (("DDPM", False), ("DDIM", False), ("FPNDM", False), ("DDPM", True), ("FPNDM", True)):
         net.use_graphs = graphs
+        net._rows.clear(); net._row_tensors.clear(); net._n_rows = 0; net._graphs.clear()    # every sampler starts cold
         dec = ClipDecoder(net, None, cfg, S.get_sampler(name))
         one = dec.generate(cond, noise_fn=noise_fn, groups=1)
         three = dec.generate(cond, noise_fn=noise_fn, groups=3)

@@ -103,6 +103,66 @@ def test_forward_full_size_b32_cycled_against_reference_golden(full_net):
         assert rel(o[j, ::60].numpy(), g["samples"][j % 9]) < 2e-4, j
 
 
+def test_every_conv_launch_of_the_full_size_forward_against_torch(full_net):
+    """Walk every DISTINCT convolution launch the full-size forward makes at the benchmark's batch sizes (B = 9:
+    configs[1]; B = 32: configs[4]) -- shape, source split, on-load transform, residual, arithmetic -- and run each
+    through the C ABI exactly as the network does (same tile / split-K / kernel choice, which depend on B) against
+    torch's fp32 convolution on the same device."""
+    import torch.nn.functional as F
+    from evc_amd import lib as L
+    seen = {}
+    for B in (9, 32):
+        x = rnd(900, B, 15, 128, 128).cuda()
+        c = rnd(901, B, 6, 128, 128).cuda()
+        prof = []
+        L.CONV_PROFILE = prof
+        try:
+            full_net.forward_label(x, 500, c)
+        finally:
+            L.CONV_PROFILE = None
+        torch.cuda.synchronize()
+        for r in prof:
+            k = tuple(sorted(r["call"].items()))
+            seen.setdefault(k, r["call"])
+    assert len(seen) > 80, len(seen)                       # 2 batch sizes x ~50 distinct layer configurations
+    worst = 0.0
+    for n, call in enumerate(seen.values()):
+        B, H, W, C0, C1, Co, K = (call[k] for k in ("B", "H", "W", "C0", "C1", "Co", "K"))
+        C = C0 + C1
+        g = torch.Generator(device="cuda").manual_seed(1000 + n)
+        x0 = torch.randn(B, H, W, C0, device="cuda", generator=g)
+        x1 = torch.randn(B, H, W, C1, device="cuda", generator=g) if C1 else None
+        w = torch.randn(Co, C, K, K, device="cuda", generator=g) / np.sqrt(C * K * K)
+        bias = torch.randn(Co, device="cuda", generator=g) if call["bias"] else None
+        res = torch.randn(B, H, W, Co, device="cuda", generator=g) if call["res"] else None
+        coef = None
+        if call["coef"]:
+            coef = (1 + 0.2 * torch.randn(B, C, device="cuda", generator=g), 0.3 * torch.randn(B, C, device="cuda", generator=g))
+        bound = None
+        if call["bound"]:
+            bound = torch.zeros(1, dtype=torch.int32, device="cuda")
+            L.gn_coeffs([L.chan_stats(x0)] + ([L.chan_stats(x1)] if C1 else []), H * W, 32 if C % 32 == 0 else 1, 1e-5,
+                        bound=bound)
+        wp = L.conv_pack_weights(w, call["arith"])
+        out = torch.empty(B, H, W, call["ld_out"], device="cuda")
+        got = L.conv2d_nhwc(x0, wp, Co, K, K, bias=bias, src1=x1, coef=coef, act_in=call["act_in"], res=res,
+                            out_scale=call["out_scale"], out=out, in_bound=bound, want_stats=call["stats"])
+        got = got[0] if call["stats"] else got
+        xin = torch.cat([x0, x1], 3) if C1 else x0
+        if coef is not None:
+            xin = xin * coef[0][:, None, None, :] + coef[1][:, None, None, :]
+        if call["act_in"] == L.ACT_SILU:
+            xin = F.silu(xin)
+        ref = F.conv2d(xin.permute(0, 3, 1, 2), w, bias, padding=K // 2).permute(0, 2, 3, 1)
+        if res is not None:
+            ref = ref + res
+        ref = ref * call["out_scale"]
+        err = float((got[..., :Co] - ref).abs().max() / ref.abs().max())
+        worst = max(worst, err)
+        assert err < 3e-5, (call, err)
+    print(f"{len(seen)} distinct conv launches, worst relative error {worst:.2e}")
+
+
 def test_full_size_ddpm_trajectory_against_reference_golden(full_net):
     """5 DDPM steps + the denoise call (6 full-size forwards, B=2, injected noise) against the reference sampler."""
     import evc_amd  # noqa: F401
