@@ -78,6 +78,17 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(CoefArgs a) {
     const int C = a.C0 + a.C1;
     const int cpg = C / a.groups;
     const int c_begin = g * cpg;
+    // the per-channel scale / shift of this thread's channel (cpg <= 256: one channel per thread) are fetched FIRST, so
+    // their latency overlaps the moment loads below instead of following the reduction
+    float pmul = 1.f, padd = 0.f;
+    if (tid < cpg) {
+        const int c = c_begin + tid;
+        if (a.mode == 1) { pmul = a.gamma[c]; padd = a.beta[c]; }
+        else if (a.mode == 2) {
+            const float* r = a.ss + (size_t)(a.row ? a.row[b] : 0) * a.ss_ld;
+            pmul = 1.f + r[c]; padd = r[C + c];
+        }
+    }
     double sm = 0.0, sq = 0.0;
     float mx = 0.f;            // largest sum-of-squares entry: sqrt(mx) bounds every element of the tensor(s)
     // channels of this group that live in source 0 / source 1
@@ -121,11 +132,14 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(CoefArgs a) {
     const float fmean = (float)mean;
     for (int i = tid; i < cpg; i += 256) {
         const int c = c_begin + i;
-        float mul = 1.f, add = 0.f;
-        if (a.mode == 1) { mul = a.gamma[c]; add = a.beta[c]; }
-        else if (a.mode == 2) {
-            const float* r = a.ss + (size_t)(a.row ? a.row[b] : 0) * a.ss_ld;
-            mul = 1.f + r[c]; add = r[C + c];
+        float mul = pmul, add = padd;
+        if (i >= 256) {                       // (groups wider than 256 channels: not in this network)
+            mul = 1.f; add = 0.f;
+            if (a.mode == 1) { mul = a.gamma[c]; add = a.beta[c]; }
+            else if (a.mode == 2) {
+                const float* r = a.ss + (size_t)(a.row ? a.row[b] : 0) * a.ss_ld;
+                mul = 1.f + r[c]; add = r[C + c];
+            }
         }
         const float ca = rstd * mul;
         a.coef_a[(size_t)b * C + c] = ca;
