@@ -35,7 +35,8 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
 #ifndef EVC_CONV_ABLATE
-#define EVC_CONV_ABLATE 0      // DIAGNOSTIC ONLY (wrong results): bit 0 = skip the weight DMA, bit 1 = skip the activation path
+#define EVC_CONV_ABLATE 0      // DIAGNOSTIC ONLY (wrong results): bit 0 = skip the weight DMA, bit 1 = skip the activation path,
+                               // bit 2 = activation loads kept but no transform / split / LDS store, bit 3 = activation loads from cache-hot addresses
 #endif
 #ifndef EVC_CONV_TM1
 #define EVC_CONV_TM1 1         // f32 kernel: grids with < 64 tiles of 128 pixels use 64-pixel tiles (0 disables, for A/B)
@@ -994,6 +995,9 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
     constexpr int NWD = WM == 2 ? (NPIECE + 3) / 4 : TN;        // WM = 4: waves 0..2*NP-1 move TN pieces each
     constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
     constexpr bool PIPE = NP == 2 && EVC_RR_PIPE;     // software-pipelined K loop (f16x3 only: bf16x6 would not fit 2 per CU)
+    // (A ring of three weight slabs DMA'd two K-steps ahead with counted vmcnt waits at every barrier -- the plain
+    // __syncthreads() carries vmcnt(0) and so waits for the slab queued at the top of the same step -- was A/B-tested and
+    // gave nothing: profiles/r02_conv_bench_rr_deep_ab.log, patch in tools/experiments/conv_rr_deep_r02.patch.)
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     const int SR = (BM / p.W) * (p.W + 2);            // staged rows: every image row of the tile + 2 halo pixels
     const int APL = SR * RB;                          // bytes per activation plane
@@ -1104,7 +1108,8 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
     auto load_a = [&]() {
         if (EVC_CONV_ABLATE & 2) return;          // diagnostic build: no activation path
         aok = (okrow >> l_ty) & 1u;
-        const unsigned o = aok ? (a_first ? off0 : off1) + (unsigned)a_delta : a_safe;
+        unsigned o = aok ? (a_first ? off0 : off1) + (unsigned)a_delta : a_safe;
+        if (EVC_CONV_ABLATE & 8) o = a_safe;      // diagnostic build: every activation load hits the same cache lines
         areg[0] = *reinterpret_cast<const float4*>(a_src + o);
         areg[1] = *reinterpret_cast<const float4*>(a_src + o + 16);
     };
@@ -1130,11 +1135,15 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
     float4 treg[2];                                  // transformed activations between tx = 1 and tx = 2 (EVC_RR_BALANCE)
     auto transform_a = [&]() {
         if (EVC_CONV_ABLATE & 2) return;
+        if (EVC_CONV_ABLATE & 4) {                // diagnostic build: loads waited for, no transform / split / LDS write
+            asm volatile("" :: "v"(areg[0].x), "v"(areg[0].w), "v"(areg[1].x), "v"(areg[1].w));
+            return;
+        }
         treg[0] = transform<MODE>(areg[0], ca[0], cs[0], aok);
         treg[1] = transform<MODE>(areg[1], ca[1], cs[1], aok);
     };
     auto store_a = [&](int ab) {
-        if (EVC_CONV_ABLATE & 2) return;
+        if (EVC_CONV_ABLATE & (2 | 4)) return;
         vec pl[NP];
         SP::split(treg[0], treg[1], xscale, pl);
         char* A = As + ab * NP * APL + a_lds;
