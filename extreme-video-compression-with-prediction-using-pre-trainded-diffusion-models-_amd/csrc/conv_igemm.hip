@@ -34,6 +34,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+#ifndef EVC_CONV_TAIL
+#define EVC_CONV_TAIL 1        // row-reuse kernel, unsplit grids of 1.x / 2.x rounds: the tiles of the last partial round are split along K
+                               // so that they fill the machine once more with short jobs (0 = off, for A/B; run-time option "tail_split")
+#endif
 #ifndef EVC_CONV_ABLATE
 #define EVC_CONV_ABLATE 0      // DIAGNOSTIC ONLY (wrong results): bit 0 = skip the weight DMA, bit 1 = skip the activation path,
                                // bit 2 = activation loads kept but no transform / split / LDS store, bit 3 = activation loads from cache-hot addresses
@@ -120,6 +124,10 @@ struct ConvK {
     float* stats;   // optional fused per-channel moments [M/64][Co][2]
     const float* w_hdr;   // f16x3 only: header of the packed weights, [0] = 1 / (activation scale * weight scale)
     const unsigned* in_bound;   // f16x3 only, optional: bit pattern of a float B with |src element| <= sqrt(B) (see in_scale)
+    // K-split TAIL of an otherwise unsplit grid (row-reuse kernel only, see conv_tile_cfg): pixel tiles >= tail_first are
+    // computed by tail_splits workgroups each (tail_sps K-steps per workgroup) that write raw partial sums to slabs of
+    // tail_rows rows [tail_splits][tail_rows][Co]; blockIdx.x >= tail_first enumerates (tile, split) pairs.
+    int tail_first, tail_splits, tail_sps, tail_rows;
 };
 
 // f16x3 on a source with no GroupNorm in front of it (raw residual stream, attention output): the caller supplies a bound
@@ -171,10 +179,12 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[TM][TN], const float4 (
 // per-channel GroupNorm moments of the output; split-K launches write raw partial sums to their slab instead.
 template <int TM, int TN, int WM = 2>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][TN], int m0, int n0, int split,
-                                              int wm, int wn, int l31, int half) {
+                                              int wm, int wn, int l31, int half, bool tail = false) {
     constexpr int BM = 32 * TM * WM;       // WM = waves along the pixel dimension (2, or 4 in the 8-wave row-reuse kernel)
     constexpr int BN = 64 * TN;
-    const bool partial = p.splits > 1;
+    const bool partial = p.splits > 1 || tail;
+    const int ws_m0 = tail ? p.tail_first * BM : 0;          // slab row 0 = this pixel
+    const size_t ws_M = tail ? (size_t)p.tail_rows : (size_t)p.M;
     // f16x3: the operands were scaled by powers of two to sit in fp16's range; undo it here (exact)
     const float ascale = p.w_hdr ? p.w_hdr[0] / in_scale(p) : 1.0f;
     const int mw = m0 + wm * 32 * TM + 4 * half;
@@ -190,7 +200,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
             for (int i = 0; i < TM; ++i) {
                 const int mb = mw + i * 32;
                 if (partial) {
-                    float* o = p.ws + ((size_t)split * p.M + mb) * p.Co + co;
+                    float* o = p.ws + ((size_t)split * ws_M + (mb - ws_m0)) * p.Co + co;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * p.Co] = acc[i][j][r] * ascale;
                 } else {
@@ -236,7 +246,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
                     if (m >= p.M) continue;
                     float v = acc[i][j][r] * ascale;
                     if (partial) {
-                        p.ws[((size_t)split * p.M + m) * p.Co + co] = v;
+                        p.ws[((size_t)split * ws_M + (m - ws_m0)) * p.Co + co] = v;
                     } else {
                         v += bias;
                         if (p.res) v += p.res[(size_t)m * p.ld_res + co];
@@ -1020,11 +1030,15 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
 #else
     const int mtile = blockIdx.x;
 #endif
-    const int m0 = mtile * BM;
+    // K-split tail (ConvK::tail_*): blockIdx.x beyond the unsplit tiles enumerates (tile, split) pairs of the last tiles
+    const bool tail = WM == 2 && (int)blockIdx.x >= p.tail_first;
+    const int tq = tail ? ((int)blockIdx.x - p.tail_first) / p.tail_splits : 0;
+    const int m0 = (tail ? p.tail_first + tq : mtile) * BM;
     const int n0 = blockIdx.y * BN;
-    const int split = blockIdx.z;
-    const int s_begin = split * p.steps_per_split;                              // multiple of 3 (host)
-    const int nst = min(p.nsteps, s_begin + p.steps_per_split) - s_begin;       // multiple of 3
+    const int split = tail ? (int)blockIdx.x - p.tail_first - tq * p.tail_splits : (int)blockIdx.z;
+    const int sps = tail ? p.tail_sps : p.steps_per_split;                      // multiple of 3 (host)
+    const int s_begin = split * sps;
+    const int nst = min(p.nsteps, s_begin + sps) - s_begin;                     // multiple of 3
     const int nmac = nst / 3;
 
     // ---- staging thread: pixel row tid/2 of the tile, channel half kh ----
@@ -1351,7 +1365,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
 #if EVC_CONV_ABLATE & 16      // diagnostic: no epilogue at run time (the accumulators stay live for the compiler)
     if (p.M > 0) return;
 #endif
-    conv_epilogue<TM, TN, WM>(p, acc, m0, n0, split, wm, wn, l31, half);
+    conv_epilogue<TM, TN, WM>(p, acc, m0, n0, split, wm, wn, l31, half, tail);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1837,7 +1851,9 @@ static int conv_validate(const evc_conv_args* a) {
 // of 128 pixels: the 8x8 layers) use the 64-pixel tile (TM = 1) first: half the split factor means half the slab
 // write + combine traffic and no half-empty tiles (A/B: 8x8 768->768 58 -> 69 TFLOP/s; on mid-size grids such
 // as 32x32 576->576 the smaller tile loses, 92 -> 84, so it is not used there).
-struct TileCfg { int tm, tn, bm, bn; long long tiles; int splits; int reuse; int steps_per_split; };
+struct TileCfg { int tm, tn, bm, bn; long long tiles; int splits; int reuse; int steps_per_split;
+                 int tail_first, tail_tiles, tail_splits, tail_sps; };    // K-split tail: pixel tiles >= tail_first (0 tiles = none)
+static int g_tail_split = EVC_CONV_TAIL;   // run-time option "tail_split"
 static int g_wide_tiles = EVC_SPLIT_WIDE_TILES;   // harness A/B switch for the 256-pixel row-reuse tiles
 static int g_no_reuse = 0;     // same: lets the harness A/B the row-reuse kernel inside one binary
 static int g_no_2d = !EVC_CONV_2D;   // 2-D patch tiles off (row tiles instead); run-time option "tiles2d"
@@ -1856,10 +1872,11 @@ static int g_force_tm = 0;     // tools/conv_bench.hip (same translation unit) s
 // the measured optimum or a configuration within a few percent of it for every layer shape of the network at
 // B = 4, 5 and 9 (e.g. 64x64 192->192, B=9: splits 3 instead of 2, 139 -> 161 TFLOP/s; 32x32 384->384: 4 -> 3,
 // 141 -> 171).
-static void split_tile_cfg(const evc_conv_args* a, long long M, long long ntile, int nsteps, TileCfg& c) {
+static void split_tile_cfg(const evc_conv_args* a, long long M, long long ntile, int nsteps, TileCfg& c, bool rr_ok) {
     const double K = (double)a->KH * a->KW * (a->C0 + a->C1);
     double best = -1.0;
     int best_tm = 2, best_s = 1;
+    c.tail_first = 0; c.tail_tiles = 0; c.tail_splits = 1; c.tail_sps = 0;
     for (int tm = 2; tm >= 1; --tm) {
         if (g_force_tm && tm != g_force_tm) continue;
         const long long tiles = ((M + 64 * tm - 1) / (64 * tm)) * ntile;
@@ -1878,6 +1895,34 @@ static void split_tile_cfg(const evc_conv_args* a, long long M, long long ntile,
     c.bm = 64 * c.tm;
     c.tiles = ((M + c.bm - 1) / c.bm) * ntile;
     c.splits = best_s;
+    // K-split TAIL (row-reuse kernel, 128-pixel tiles, caller did not fix the split): R >= 1 full rounds of unsplit tiles,
+    // then the tiles of the partial round split `ts` ways so that they fill the machine once more with short jobs --
+    // instead of splitting EVERY tile (slabs + combine for the whole output) or leaving a mostly idle last round.
+    // Same time model as above: rounds x (steps + 6) x slab penalty (the tail's slabs only cover the tail's rows).
+    if (rr_ok && g_tail_split && a->splits <= 0 && !g_force_tm && M % 128 == 0) {
+        const long long tm_all = M / 128, wgs = tm_all * ntile;
+        const long long R = wgs / 512;
+        const long long main_m = R * 512 / ntile, tail_m = tm_all - main_m;
+        const int unit = 3 * 9;                                   // a tail workgroup runs >= 3 chunks' worth of K-steps
+        if (R >= 1 && tail_m > 0 && nsteps >= 2 * unit) {
+            int ts = (int)(512 / (tail_m * ntile));
+            if (ts > nsteps / unit) ts = nsteps / unit;
+            if (ts >= 2) {
+                int sps = (nsteps + ts - 1) / ts;
+                sps = (sps + 2) / 3 * 3;
+                ts = (nsteps + sps - 1) / sps;
+                const double x_t = (double)(tail_m * ntile * ts) / 512.0;
+                const double t_tail = (double)R * (nsteps + 6.0) +
+                                      (double)(long long)(x_t + 0.999999) * (sps + 6.0) * (1.0 + 40.0 * ts / K);
+                const double work = (double)wgs / 512.0 * nsteps;
+                const double score_tail = work / t_tail;
+                if (ts >= 2 && score_tail > best * 1.02) {
+                    c.tm = 2; c.bm = 128; c.tiles = wgs; c.splits = 1;
+                    c.tail_first = (int)main_m; c.tail_tiles = (int)tail_m; c.tail_splits = ts; c.tail_sps = sps;
+                }
+            }
+        }
+    }
 }
 
 static inline bool is_split_arith(int arith) { return arith == EVC_ARITH_BF16X6 || arith == EVC_ARITH_F16X3; }
@@ -1916,14 +1961,15 @@ static TileCfg conv_tile_cfg(const evc_conv_args* a) {
     c.reuse = 0;
     if (is_split_arith(a->arith)) {
         const int np = arith_planes(a->arith);
-        split_tile_cfg(a, M, ntile, nsteps, c);
         // row-reuse kernel: 3x3 filters, 128-pixel tiles made of whole image rows (and an LDS image that fits: W >= 4)
-        if (!g_no_reuse && a->KH == 3 && a->KW == 3 && c.tm == 2 && a->W >= 4 && 128 % a->W == 0 &&
-            rr_lds_bytes(np, 128, a->W, c.bn) <= LDS_CAP) c.reuse = 1;
+        const bool rr_ok = !g_no_reuse && a->KH == 3 && a->KW == 3 && a->W >= 4 && 128 % a->W == 0 &&
+                           rr_lds_bytes(np, 128, a->W, c.bn) <= LDS_CAP;
+        split_tile_cfg(a, M, ntile, nsteps, c, rr_ok && g_no_2d);
+        if (rr_ok && c.tm == 2) c.reuse = 1;
         // 8-wave / 256-pixel form of the row-reuse kernel (one workgroup per CU = 256 slots).  Measured (B=8, 128x128:
         // exactly 2 rounds) +4-5 %; at B=9 (2.25 rounds) -5 %: the coarser tile makes the tail worse.  So: unsplit
         // grids that are a whole number of >= 2 rounds, or long enough (>= 6 rounds) for the tail not to matter.
-        if (c.reuse && c.splits == 1 && g_wide_tiles && M % 256 == 0 && rr_lds_bytes(np, 256, a->W, c.bn) <= LDS_CAP) {
+        if (c.reuse && c.splits == 1 && !c.tail_tiles && g_wide_tiles && M % 256 == 0 && rr_lds_bytes(np, 256, a->W, c.bn) <= LDS_CAP) {
             const long long t256 = (M / 256) * ntile;
             if ((t256 >= 512 && t256 % 256 == 0) || t256 >= 6 * 256) {
                 c.bm = 256;
@@ -1938,6 +1984,7 @@ static TileCfg conv_tile_cfg(const evc_conv_args* a) {
             c.tiles = (M / 128) * ntile;
         }
     } else {
+        c.tail_first = 0; c.tail_tiles = 0; c.tail_splits = 1; c.tail_sps = 0;
         c.tm = (!EVC_CONV_TM1 || ((M + 127) / 128) * ntile >= 64) ? 2 : 1;
         if (g_force_tm) c.tm = g_force_tm;
         c.bm = 64 * c.tm;
@@ -1968,6 +2015,7 @@ extern "C" int evc_conv_set_option(const char* name, int value) {
     if (is("tiles2d")) { g_no_2d = !value; return EVC_OK; }
     if (is("wide_tiles")) { g_wide_tiles = value; return EVC_OK; }
     if (is("row_reuse")) { g_no_reuse = !value; return EVC_OK; }
+    if (is("tail_split")) { g_tail_split = value; return EVC_OK; }
     return EVC_EINVAL;
 }
 
@@ -1982,6 +2030,8 @@ extern "C" int evc_conv_stats_splits(const evc_conv_args* a) {
     if (HW % 64 != 0) return 0;
     const TileCfg c = conv_tile_cfg(a);
     if (c.splits > 1) return HW / 64;                          // produced by the split-K combine kernel (64-pixel runs)
+    // (a K-split tail mixes both producers: the epilogue of the unsplit tiles and the combine of the tail write the same
+    // 64-pixel runs, the checks below hold for it because its tiles are full 128-pixel tiles)
     const long long M = (long long)a->B * HW;
     const int CoPad = evc_conv_co_pad(a->Co);
     if (M % c.bm != 0 || a->Co != CoPad || a->Co % c.bn != 0) return 0;
@@ -1989,10 +2039,11 @@ extern "C" int evc_conv_stats_splits(const evc_conv_args* a) {
 }
 
 extern "C" long long evc_conv_workspace_bytes(const evc_conv_args* a) {
-    const int s = evc_conv_choose_splits(a);
-    if (s < 0) return s;
-    if (s == 1) return 0;
-    return (long long)s * a->B * a->H * a->W * a->Co * (long long)sizeof(float);
+    if (conv_validate(a) != EVC_OK) return EVC_EINVAL;
+    const TileCfg c = conv_tile_cfg(a);
+    if (c.tail_tiles) return (long long)c.tail_splits * c.tail_tiles * 128 * a->Co * (long long)sizeof(float);
+    if (c.splits == 1) return 0;
+    return (long long)c.splits * a->B * a->H * a->W * a->Co * (long long)sizeof(float);
 }
 
 // Kernels that take more than the default 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised,
@@ -2117,11 +2168,17 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     k.splits = cfg.splits;
     k.steps_per_split = cfg.steps_per_split;
     k.ws = ws;
-    if (k.splits > 1 && !ws) return EVC_EINVAL;
+    if ((k.splits > 1 || cfg.tail_tiles) && !ws) return EVC_EINVAL;
     k.stats = k.splits > 1 ? nullptr : a->stats_out;   // with split-K the combine kernel writes them
     if (a->stats_out && evc_conv_stats_splits(a) == 0) return EVC_EINVAL;
+    k.tail_first = 0x7fffffff; k.tail_splits = 1; k.tail_sps = 0; k.tail_rows = 0;
+    if (cfg.tail_tiles) {
+        k.tail_first = cfg.tail_first; k.tail_splits = cfg.tail_splits; k.tail_sps = cfg.tail_sps;
+        k.tail_rows = cfg.tail_tiles * 128;
+    }
 
     dim3 grid((k.M + cfg.bm - 1) / cfg.bm, k.CoPad / cfg.bn, k.splits);
+    if (cfg.tail_tiles) grid.x = cfg.tail_first + cfg.tail_tiles * cfg.tail_splits;
     hipStream_t st = (hipStream_t)stream;
     if (is_split_arith(a->arith)) {
         const int np = arith_planes(a->arith);
@@ -2172,6 +2229,14 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((k.M + 63) / 64, (k.Co + 63) / 64), dim3(1024), 0, st, ws,
                            k.splits, k.M, k.Co, a->bias, a->res, a->ld_res, a->out_scale, a->act_out, a->out,
                            a->ld_out, a->stats_out);
+        if (hipGetLastError() != hipSuccess) return EVC_ELAUNCH;
+    }
+    if (cfg.tail_tiles) {       // combine of the tail's rows only
+        const size_t m0 = (size_t)cfg.tail_first * 128;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((k.tail_rows + 63) / 64, (k.Co + 63) / 64), dim3(1024), 0, st, ws,
+                           k.tail_splits, k.tail_rows, k.Co, a->bias, a->res ? a->res + m0 * a->ld_res : nullptr, a->ld_res,
+                           a->out_scale, a->act_out, a->out + m0 * a->ld_out, a->ld_out,
+                           a->stats_out ? a->stats_out + (m0 / 64) * k.Co * 2 : nullptr);
         if (hipGetLastError() != hipSuccess) return EVC_ELAUNCH;
     }
     return EVC_OK;

@@ -467,6 +467,15 @@ def conv_fused_stats_splits(B, H, W, Ci, Co, KH, KW, splits=0, arith=None):
     return hip_lib(require_device=False).evc_conv_stats_splits(ctypes.byref(a))
 
 
+def conv_workspace_bytes(B, H, W, Ci, Co, KH, KW, splits=0, arith=None):
+    """Bytes of split-K slabs ``conv2d_nhwc`` takes for this shape: 0 for an unsplit grid, splits x output for split-K,
+    tail splits x tail rows when only the last partial round of tiles is split (C query, no launch)."""
+    d = c_void_p(16)
+    a = ConvArgs(d, None, Ci, 0, 0, 0, None, None, ACT_NONE, d, None, None, 0, 1.0, ACT_NONE, d, Co, B, H, W, Co, KH,
+                 KW, splits, None, default_arith() if arith is None else arith, None)
+    return hip_lib(require_device=False).evc_conv_workspace_bytes(ctypes.byref(a))
+
+
 def attention(qkv, C, heads, out=None, bounds=None):
     """qkv: (B, N, 3C) with q | k | v concatenated along channels; returns (B, N, C).  ``bounds``: three int32 words
     (element bounds of q, k, v from ``moments_bound``) select the fp16-split kernel; None the f32-MFMA one."""

@@ -151,6 +151,37 @@ def test_conv3x3_row_reuse_shapes(L, split_arith, B, H, W, C0, C1, Co, splits):
     assert rel(nchw(out2), ref2) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,C0,C1,Co", [(9, 64, 64, 64, 32, 384),     # 576 workgroups: one round + 32 tiles x 2 n-tiles split 2 ways
+                                             (5, 128, 128, 96, 0, 192),    # 640 workgroups: one round + 128 tiles split 2 ways
+                                             (5, 128, 128, 48, 48, 128)])  # 128-wide N tile (two 32-column MFMA tiles per wave)
+def test_conv3x3_k_split_tail(L, split_arith, B, H, W, C0, C1, Co):
+    """Unsplit grids of 1.x rounds: the pixel tiles of the partial last round are split along K inside the same launch
+    (conv_tile_cfg, option "tail_split"), their slabs combined by a second kernel over the tail's rows only.  Outputs,
+    fused moments (two producers: epilogue and combine) and the untouched main tiles against torch fp32 and against
+    the same launch with the tail switched off."""
+    x0 = rnd(60, B, C0, H, W).cuda()
+    x1 = rnd(61, B, C1, H, W).cuda() if C1 else None
+    C = C0 + C1
+    a, s = (1 + 0.2 * rnd(62, B, C)).cuda(), (0.3 * rnd(63, B, C)).cuda()
+    w = (rnd(64, Co, C, 3, 3) / np.sqrt(9 * C)).cuda()
+    b, res = rnd(65, Co).cuda(), rnd(66, B, Co, H, W).cuda()
+    wp = L.conv_pack_weights(w, split_arith)
+    kw = dict(bias=b, src1=None if x1 is None else nhwc(x1), coef=(a, s), act_in=L.ACT_SILU, res=nhwc(res), out_scale=0.5)
+    assert L.conv_workspace_bytes(B, H, W, C, Co, 3, 3, arith=split_arith) > 0          # the tail is in use ...
+    assert L.conv_workspace_bytes(B, H, W, C, Co, 3, 3, arith=split_arith) < B * H * W * Co * 4   # ... and only the tail has slabs
+    out, st = L.conv2d_nhwc(nhwc(x0), wp, Co, 3, 3, want_stats=True, **kw)
+    L.conv_set_option("tail_split", 0)
+    try:
+        base, st0 = L.conv2d_nhwc(nhwc(x0), wp, Co, 3, 3, want_stats=True, splits=1, **kw)
+    finally:
+        L.conv_set_option("tail_split", 1)
+    assert rel(out, base) < 2e-6
+    assert rel(st.double().sum(1).float(), st0.double().sum(1).float()) < 1e-5
+    xin = torch.cat([x0, x1], 1).cpu() if C1 else x0.cpu()
+    ref = (F.conv2d(silu_affine(xin, a.cpu(), s.cpu()), w.cpu(), b.cpu(), padding=1) + res.cpu()) * 0.5
+    assert rel(nchw(out), ref) < 1e-5
+
+
 @pytest.mark.parametrize("B,H,W,C0,C1,Co,splits", [(2, 32, 32, 32, 16, 192, 0), (1, 64, 64, 16, 0, 128, 2), (1, 128, 128, 16, 16, 64, 0),
                                                     (3, 16, 16, 48, 0, 192, 3), (2, 8, 32, 16, 0, 192, 0)])
 def test_conv3x3_2d_patch_tiles(L, split_arith, B, H, W, C0, C1, Co, splits):
