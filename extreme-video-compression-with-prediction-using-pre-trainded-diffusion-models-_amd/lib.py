@@ -167,6 +167,11 @@ def hip_lib(require_device=True):
     global _hip
     if _hip is None:
         _hip = _load(HIP_SO, HIP_SYMBOLS, "libevc_hip.so")
+        # A/B switches of the convolution dispatch (same-box comparisons: tools/ab_*.sh): EVC_CONV_OPTIONS="tail_split=0,..."
+        for item in filter(None, os.environ.get("EVC_CONV_OPTIONS", "").split(",")):
+            name, _, value = item.partition("=")
+            if _hip.evc_conv_set_option(name.strip().encode(), int(value or 1)) != 0:
+                raise ValueError(f"EVC_CONV_OPTIONS: unknown convolution option {name!r}")
     if require_device:
         if not torch.cuda.is_available():
             raise EvcLibraryError("no HIP device visible: the evc_amd compute path is gfx950-only (no CPU fallback)")
@@ -355,7 +360,7 @@ def conv_pack_weights(w, arith=None):
 
 
 def conv_set_option(name, value):
-    """Dispatch switches of the convolution ("tiles2d", "wide_tiles", "row_reuse"): include/evc_hip.h."""
+    """Dispatch switches of the convolution ("tiles2d", "wide_tiles", "row_reuse", "tail_split"): include/evc_hip.h."""
     _check(hip_lib(require_device=False).evc_conv_set_option(name.encode(), int(value)), "evc_conv_set_option")
 
 
