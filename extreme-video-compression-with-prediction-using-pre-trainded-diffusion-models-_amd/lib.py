@@ -13,6 +13,8 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.path.join(HERE, "lib", "libevc_hip.so")
+if os.environ.get("EVC_HIP_SO"):       # A/B builds of the kernel library (tools/ab_lib.sh); in-tree paths only
+    HIP_SO = os.path.abspath(os.environ["EVC_HIP_SO"])
 RANS_SO = os.path.join(HERE, "lib", "libevc_rans.so")
 
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
