@@ -261,6 +261,32 @@ def gen_unet_ddpm():
     save("unet_ddpm", **out)
 
 
+def gen_forward_spade():
+    """The SPADE-conditioned variant (``model.spade: true`` -> SPADE_NCSNpp, ncsnpp_more.py:396-718), reduced size:
+    conditioning frames enter through per-act-norm gamma/beta maps instead of the input concat."""
+    from models.better.ncsnpp_more import UNetMore_DDPM
+    from oracle import scorenet_spade as OS
+    cfg = ref_config(32, 32, 32)
+    cfg.model.spade = True
+    cfg.model.spade_dim = 32
+    net = UNetMore_DDPM(cfg).eval()
+    d = Dims(ngf=32, n_head_channels=32, image_size=32)
+    p = OS.seeded_params(d, 81, spade_dim=32)
+    own = dict(net.named_parameters())
+    assert set(own) == set(p), sorted(set(own) ^ set(p))[:8]
+    assert [k for k in own] == [k for k in p], "state_dict order"
+    for k, v in p.items():
+        assert tuple(own[k].shape) == tuple(v.shape), k
+    missing, unexpected = net.load_state_dict(p, strict=False)
+    assert not unexpected and all(m in ("betas", "alphas", "alphas_prev", "unet.sigmas") for m in missing), missing
+    x, cond = rnd(82, 2, 15, 32, 32), rnd(83, 2, 6, 32, 32)
+    with torch.no_grad():
+        o0 = net(x, torch.tensor([0, 0]), cond=cond)
+        o1 = net(x, torch.tensor([990, 3]), cond=cond)
+        o2 = net(x, torch.tensor([-0.5, -0.5]), cond=cond)
+    save("forward_spade", out_t0=o0, out_t990_3=o1, out_tm05=o2)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -268,7 +294,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     gens = dict(schedule=gen_schedule, fir=gen_fir, blocks=gen_blocks, forward_reduced=gen_forward_reduced,
                 samplers=gen_samplers, forward_full=gen_forward_full, forward_full_b9=gen_forward_full_b9,
-                traj_full=gen_traj_full, unet_ddpm=gen_unet_ddpm)
+                traj_full=gen_traj_full, unet_ddpm=gen_unet_ddpm, forward_spade=gen_forward_spade)
     for name, fn in gens.items():
         if a.only and name != a.only:
             continue

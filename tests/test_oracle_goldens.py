@@ -151,3 +151,18 @@ def test_unet_ddpm_oracle_matches_reference_goldens():
     traj = OS.ddpm(x.clone(), lambda xx, t: OU.forward(p, d, xx, t, cond=cond), OSch.base_schedule(), subsample_steps=4,
                    noise_fn=lambda i, xx: noises[i])
     assert float(np.abs(traj.numpy() - g["ddpm_tc"]).max() / np.abs(g["ddpm_tc"]).max()) < 1e-4
+
+
+def test_spade_scorenet_oracle_matches_reference_goldens():
+    """SPADE-conditioned NCSN++ (``model.spade: true``, reference SPADE_NCSNpp): oracle forward at integer, mixed and
+    fractional labels against outputs of the imported reference on the same seeded weights."""
+    from oracle import scorenet as OSN, scorenet_spade as OSP
+    g = golden("forward_spade")
+    d = OSN.Dims(ngf=32, n_head_channels=32, image_size=32)
+    p = OSP.seeded_params(d, 81, spade_dim=32)
+    x, cond = rnd(82, 2, 15, 32, 32), rnd(83, 2, 6, 32, 32)
+    for key, labels in (("out_t0", [0, 0]), ("out_t990_3", [990, 3]), ("out_tm05", [-0.5, -0.5])):
+        out = OSP.forward(p, d, x, torch.tensor(labels), cond, spade_dim=32)
+        ref = g[key]
+        assert float(np.abs(out.numpy() - ref).max() / np.abs(ref).max()) < 2e-5, key
+    assert not np.array_equal(g["out_t0"], g["out_t990_3"])
