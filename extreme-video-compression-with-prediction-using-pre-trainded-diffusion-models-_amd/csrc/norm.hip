@@ -191,7 +191,56 @@ __global__ void affine_act_kernel(const float* __restrict__ x, float* __restrict
     }
 }
 
+// SPADE act-norm (reference models/better/layerspp.py:152-173 MySPADE + :518-549 get_act_norm, norm == 'spade'):
+//   y = act( [ (x*a + s) * G + Bt ] * (1 + scale) + shift )
+// a, s: parameter-free GroupNorm coefficients per (sample, channel); G = 1 + gamma(cond), Bt = beta(cond): per-pixel maps
+// (they depend on the conditioning frames only, the host computes them once per chunk); scale / shift: the AdaGN row of
+// the sample's step label (absent for the network's final norm).
+__global__ void spade_act_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ ca,
+                                 const float* __restrict__ cs, int ld_coef, const float* __restrict__ gmap,
+                                 const float* __restrict__ bmap, int ld_map, const float* __restrict__ ss_scale,
+                                 const float* __restrict__ ss_shift, int ld_ss, const int* __restrict__ row, int act,
+                                 int HW, int C, int ld_out, size_t total4) {
+    const int C4 = C >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const size_t pix = i / C4;
+        const int b = (int)(pix / HW);
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 a = *reinterpret_cast<const float4*>(ca + (size_t)b * ld_coef + 4 * c4);
+        const float4 s = *reinterpret_cast<const float4*>(cs + (size_t)b * ld_coef + 4 * c4);
+        const float4 g = *reinterpret_cast<const float4*>(gmap + pix * (size_t)ld_map + 4 * c4);
+        const float4 t = *reinterpret_cast<const float4*>(bmap + pix * (size_t)ld_map + 4 * c4);
+        v.x = (v.x * a.x + s.x) * g.x + t.x; v.y = (v.y * a.y + s.y) * g.y + t.y;
+        v.z = (v.z * a.z + s.z) * g.z + t.z; v.w = (v.w * a.w + s.w) * g.w + t.w;
+        if (ss_scale) {
+            const size_t r = (size_t)(row ? row[b] : 0) * ld_ss + 4 * c4;
+            const float4 sc = *reinterpret_cast<const float4*>(ss_scale + r);
+            const float4 sh = *reinterpret_cast<const float4*>(ss_shift + r);
+            v.x = v.x * (1.0f + sc.x) + sh.x; v.y = v.y * (1.0f + sc.y) + sh.y;
+            v.z = v.z * (1.0f + sc.z) + sh.z; v.w = v.w * (1.0f + sc.w) + sh.w;
+        }
+        v.x = act_fn(v.x, act); v.y = act_fn(v.y, act); v.z = act_fn(v.z, act); v.w = act_fn(v.w, act);
+        *reinterpret_cast<float4*>(y + pix * (size_t)ld_out + 4 * c4) = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int evc_spade_act_nhwc_f32(const float* x, float* y, const float* coef_a, const float* coef_s, int ld_coef,
+                                      const float* gmap, const float* bmap, int ld_map, const float* ss_scale,
+                                      const float* ss_shift, int ld_ss, const int* row, int act, int B, int HW, int C,
+                                      int ld_out, void* stream) {
+    if (!x || !y || !coef_a || !coef_s || !gmap || !bmap || B <= 0 || HW <= 0 || C <= 0 || (C & 3)) return EVC_EINVAL;
+    if ((ss_scale == nullptr) != (ss_shift == nullptr)) return EVC_EINVAL;
+    if (ld_coef < C || ld_map < C || ld_out < C || ((ld_coef | ld_map | ld_out) & 3)) return EVC_EINVAL;
+    if (ss_scale && (ld_ss < C || (ld_ss & 3))) return EVC_EINVAL;
+    const size_t total4 = (size_t)B * HW * (C >> 2);
+    const int grid = (int)((total4 + 255) / 256 > 4096 ? 4096 : (total4 + 255) / 256);
+    hipLaunchKernelGGL(spade_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, coef_a, coef_s, ld_coef,
+                       gmap, bmap, ld_map, ss_scale, ss_shift, ld_ss, row, act, HW, C, ld_out, total4);
+    return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
+}
 
 extern "C" int evc_chan_stats_f32(const float* x, float* partial, int B, int HW, int C, int nsplit, void* stream) {
     if (!x || !partial || B <= 0 || HW <= 0 || C <= 0 || (C & 3) || nsplit <= 0 || nsplit > HW) return EVC_EINVAL;

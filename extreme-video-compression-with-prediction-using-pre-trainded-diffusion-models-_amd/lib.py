@@ -109,6 +109,8 @@ HIP_SYMBOLS = {
     "evc_conv_packed_bytes": (c_longlong, [c_int, c_int, c_int, c_int, c_int]),
     "evc_conv_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "evc_conv_set_option": (c_int, [c_char_p, c_int]),
+    "evc_spade_act_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                       c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "evc_conv_choose_splits": (c_int, [POINTER(ConvArgs)]),
     "evc_conv_stats_splits": (c_int, [POINTER(ConvArgs)]),
     "evc_conv_workspace_bytes": (c_longlong, [POINTER(ConvArgs)]),
@@ -339,6 +341,31 @@ def affine_act(x, coef, act, out=None, coef_col=0):
     ps = None if cs is None else c_void_p(cs.data_ptr() + 4 * coef_col)
     _check(L.evc_affine_act_nhwc_f32(fptr(x), po, pa, ps, act, B, H * W, C, ldc, ldo, stream_ptr()),
            "evc_affine_act_nhwc_f32")
+    return out.t if isinstance(out, Cols) else out
+
+
+def spade_act(x, coef, maps, ctot, col=0, ss=None, row=None, act=ACT_SILU, out=None):
+    """SPADE act-norm of one part of a (virtual) concat: ``x`` (B, H, W, C) contiguous; ``coef`` = (a, s), each (B, ctot);
+    ``maps`` (B, H, W, 2*ctot) = [1 + gamma | beta]; ``ss`` the AdaGN table slice (rows, 2*ctot) = [scale | shift] (None:
+    no time embedding); ``col`` the part's channel offset inside the concat; ``out`` a tensor or ``Cols`` slice."""
+    L = hip_lib()
+    B, H, W, C = x.shape
+    assert x.is_contiguous() and maps.is_contiguous() and maps.shape == (B, H, W, 2 * ctot) and col + C <= ctot
+    if out is None:
+        out = torch.empty_like(x)
+    po, Cout, ldo, _ = _src(out)
+    assert Cout == C
+    ca, cs = coef
+    assert ca.shape == (B, ctot) and cs.shape == (B, ctot)
+    off = lambda t, c: c_void_p(t.data_ptr() + 4 * c)
+    ps = psh = None
+    ld_ss = 0
+    if ss is not None:
+        assert ss.shape[1] == 2 * ctot and ss.stride(1) == 1
+        ps, psh, ld_ss = off(ss, col), off(ss, ctot + col), ss.stride(0)
+    _check(L.evc_spade_act_nhwc_f32(fptr(x), po, off(ca, col), off(cs, col), ctot, off(maps, col), off(maps, ctot + col),
+                                    2 * ctot, ps, psh, ld_ss, fptr(row, torch.int32), act, B, H * W, C, ldo, stream_ptr()),
+           "evc_spade_act_nhwc_f32")
     return out.t if isinstance(out, Cols) else out
 
 

@@ -106,6 +106,8 @@ def _pad16(c):
 class ScoreNet:
     """HIP implementation of ``UNetMore_DDPM`` (eval mode, dropout 0, spade/cond_emb/noise_in_cond off)."""
 
+    SPADE = False      # scorenet_spade.SpadeScoreNet: conditioning through SPADE act-norms (model.spade: true)
+
     def __init__(self, config, state_dict, device="cuda", prefix="", preactivate=False, use_graphs=False):
         L.hip_lib()   # fail loudly before touching anything else
         # preactivate=False: AdaGN + SiLU is fused into the 3x3 convolutions' operand load (evaluated once per
@@ -119,10 +121,11 @@ class ScoreNet:
         self.d = dims_from_config(config)
         self.type = getattr(config.model, "type", "v1")
         m = config.model
-        if getattr(m, "spade", False) or getattr(m, "cond_emb", False) or getattr(m, "noise_in_cond", False) or \
-                getattr(m, "output_all_frames", False) or m.arch != "unetmore":
-            raise NotImplementedError("only the arch=unetmore / concat-conditioning configuration of "
-                                      "configs/mine.yml is on the hot path (SURVEY.md section 2)")
+        if bool(getattr(m, "spade", False)) != self.SPADE or getattr(m, "cond_emb", False) or \
+                getattr(m, "noise_in_cond", False) or getattr(m, "output_all_frames", False) or m.arch != "unetmore":
+            raise NotImplementedError("only arch=unetmore without cond_emb / noise_in_cond / output_all_frames is built: "
+                                      "the concat-conditioned network of configs/mine.yml (ScoreNet) and its SPADE "
+                                      "variant (SpadeScoreNet); 3-D / pseudo-3-D archs are not (SURVEY.md section 2)")
         # schedule buffers exactly as ncsnpp_more.py:735-739 builds them (CPU float32; the samplers index them)
         if getattr(m, "sigma_dist", "linear") != "linear":
             raise NotImplementedError("sigma_dist != linear")
@@ -130,6 +133,8 @@ class ScoreNet:
         self.alphas = torch.cumprod(1 - self.betas.flip(0), 0).flip(0)
         self.alphas_prev = torch.cat([self.alphas[1:], torch.tensor([1.0]).to(self.alphas)])
         self.program = build_program(self.d)
+        if self.SPADE:     # the conditioning frames do not enter through the input (ncsnpp_more.py:519, :593-594)
+            self.program[2]["cin"] = self.d.channels * self.d.num_frames
         self._load(state_dict, prefix + "unet.all_modules.")
         self._rows = {}          # label value -> row of the AdaGN table
         self._row_tensors = {}   # (row, B) -> int32 device tensor
@@ -191,6 +196,7 @@ class ScoreNet:
                     dense_w.append(dw); dense_b.append(db)
                     e[f"ss{j}"] = (off, dw.shape[0] // 2)
                     off += dw.shape[0]
+                    self._load_actnorm(e, j, f"{n}.{key}", g)
                 # Conv_0 / Conv_1 read AdaGN + SiLU outputs (directly or through the FIR resampler): O(1) operands
                 e["w0"] = self._pack_conv(g(n + ".Conv_0.weight"), bounded=True); e["b0"] = self._dev(g(n + ".Conv_0.bias"))
                 e["w1"] = self._pack_conv(g(n + ".Conv_1.weight"), bounded=True); e["b1"] = self._dev(g(n + ".Conv_1.bias"))
@@ -210,11 +216,17 @@ class ScoreNet:
                                  # output projection: |attention output| <= max |v|, bounded through v's moments
                                  wo=self._pack_conv(ws[3].t()[:, :, None, None], bounded=True), bo=self._dev(bs[3]))
             elif k == "norm":
-                self.w[i] = dict(gamma=self._dev(g(n + ".Norm_0.weight")), beta=self._dev(g(n + ".Norm_0.bias")))
+                self.w[i] = self._load_final_norm(n, g)
         self.ss_total = off
         self.temb_dim = dense_w[0].shape[1]
         self.dense_w = self._pack_conv(torch.cat(dense_w, 0)[:, :, None, None])
         self.dense_b = self._dev(torch.cat(dense_b, 0))
+
+    def _load_actnorm(self, e, j, name, g):
+        """Hook: extra parameters of act-norm ``j`` of a res-block (none here; SPADE maps in SpadeScoreNet)."""
+
+    def _load_final_norm(self, n, g):
+        return dict(gamma=self._dev(g(n + ".Norm_0.weight")), beta=self._dev(g(n + ".Norm_0.bias")))
 
     # ------------------------------------------------------------------------------------------
     def _embedding(self, labels):
@@ -384,7 +396,7 @@ class ScoreNet:
             self._bound_next = 0
         i = 2
         m = prog[i]
-        xin = L.pack_nchw_to_nhwc(x, cond, self.w[i]["cin_pad"])
+        xin = self._pack_input(x, cond, self.w[i]["cin_pad"])
         hs = [_Act(*L.conv2d_nhwc(xin, self.w[i]["w"], m["cout"], 3, 3, bias=self.w[i]["b"], want_stats=True))]
         i += 1
         n_lvl = len(d.ch_mult)
@@ -408,17 +420,23 @@ class ScoreNet:
             if lvl != 0:
                 h = self._res(i, prog[i], h, None, rows); i += 1
         assert not hs
-        e = self.w[i]
-        Bh, Hh, Wh, C = h.t.shape
-        coef = L.gn_coeffs([h.stats()], Hh * Wh, num_groups(C), 1e-5, mode=1, gamma=e["gamma"], beta=e["beta"])
-        i += 1
-        m = prog[i]
-        co = m["cout"]
-        out = torch.empty((B, H, W, _pad16(co)), device=x.device, dtype=torch.float32)
-        L.conv2d_nhwc(h.t, self.w[i]["w"], co, 3, 3, bias=self.w[i]["b"], coef=coef, act_in=L.ACT_SILU, out=out)
-        i += 1
-        assert i == len(prog)
+        out, co = self._final(i, h)
+        assert i + 2 == len(prog)
         return L.nhwc_to_nchw(out, co)
+
+    def _pack_input(self, x, cond, cin_pad):
+        """Network input: frames to denoise and conditioning frames concatenated along channels (ncsnpp_more.py:256-257)."""
+        return L.pack_nchw_to_nhwc(x, cond, cin_pad)
+
+    def _final(self, i, h):
+        """Final GroupNorm + SiLU fused into the output convolution's load (ncsnpp_more.py:380-388)."""
+        e = self.w[i]
+        B, H, W, C = h.t.shape
+        coef = L.gn_coeffs([h.stats()], H * W, num_groups(C), 1e-5, mode=1, gamma=e["gamma"], beta=e["beta"])
+        co = self.program[i + 1]["cout"]
+        out = torch.empty((B, H, W, _pad16(co)), device=h.t.device, dtype=torch.float32)
+        L.conv2d_nhwc(h.t, self.w[i + 1]["w"], co, 3, 3, bias=self.w[i + 1]["b"], coef=coef, act_in=L.ACT_SILU, out=out)
+        return out, co
 
     def _forward(self, x, rows, cond):
         """``forward_rows`` through a captured HIP graph when enabled (static input buffers, one replay)."""
@@ -475,10 +493,14 @@ class ScoreNet:
 
 
 def build_score_network(config, state_dict, device="cuda", **kw):
-    """``config.model.arch``: "unetmore" -> ScoreNet (the network the reference CLI hard-codes, city_sender.py:311-312);
-    "unet" -> UNetDDPM (reference models/unet.py, upstream MCVD's name for it).  Both plug into the same samplers."""
+    """``config.model.arch``: "unetmore" -> ScoreNet (the network the reference CLI hard-codes, city_sender.py:311-312), or
+    SpadeScoreNet when ``config.model.spade`` (ncsnpp_more.py:730-733); "unet" -> UNetDDPM (reference models/unet.py,
+    upstream MCVD's name for it).  All plug into the same samplers."""
     arch = getattr(config.model, "arch", "unetmore")
     if arch == "unet":
         from .unet_ddpm import UNetDDPM
         return UNetDDPM(config, state_dict, device=device)
+    if getattr(config.model, "spade", False):
+        from .scorenet_spade import SpadeScoreNet
+        return SpadeScoreNet(config, state_dict, device=device, **kw)
     return ScoreNet(config, state_dict, device=device, **kw)

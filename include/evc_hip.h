@@ -107,6 +107,18 @@ int evc_moments_bound_f32(const float* part, int nsplit, int C, int c_begin, int
 int evc_affine_act_nhwc_f32(const float* x, float* y, const float* coef_a, const float* coef_s, int act, int B,
                             int HW, int C, int ld_coef, int ld_out, void* stream);
 
+/* SPADE act-norm of the conditioning-by-normalisation variant of the score network (reference
+ * models/better/layerspp.py:152-173 MySPADE.forward + :518-549 get_act_norm.forward with norm == 'spade'):
+ *   y = act( [ (x*coef_a[b][c] + coef_s[b][c]) * gmap[pixel][c] + bmap[pixel][c] ] * (1 + scale[row[b]][c]) + shift[row[b]][c] )
+ * coef_*: parameter-free GroupNorm coefficients (evc_gn_coeffs_f32 mode 0, eps 1e-6); gmap = 1 + gamma(cond) and
+ * bmap = beta(cond): NHWC maps with row stride ld_map (they depend on the conditioning frames only); ss_scale / ss_shift:
+ * AdaGN table columns with row stride ld_ss, NULL for the final norm (no time embedding); `row` NULL = row 0.  x is
+ * contiguous [B*HW][C]; all pointers may be offset to a channel slice of wider buffers (ld_* are the full widths). */
+int evc_spade_act_nhwc_f32(const float* x, float* y, const float* coef_a, const float* coef_s, int ld_coef,
+                           const float* gmap, const float* bmap, int ld_map, const float* ss_scale,
+                           const float* ss_shift, int ld_ss, const int* row, int act, int B, int HW, int C, int ld_out,
+                           void* stream);
+
 /* ---- convolution as implicit GEMM on the matrix cores -----------------------------------------
  * Two arithmetics, both fp32 in / fp32 accumulate (see EVC_ARITH_* above); the packing of the weights selects one:
  *   EVC_ARITH_BF16X6 (default of the Python host): conv_split_rr_kernel for 3x3 filters on tiles made of whole image

@@ -273,3 +273,56 @@ def test_alt_model_unet_ddpm_against_reference_goldens():
             out = sampler.ddpm_sampler(x, net, cond=cond, subsample_steps=4, denoise=True, clip_before=True,
                                        final_only=True, noise_fn=lambda i, xx: noises[i])
             assert out.shape == g["ddpm_tc"].shape and rel(out, g["ddpm_tc"]) < 5e-4
+
+
+def build_spade(ngf, head, image_size, seed, spade_dim):
+    import evc_amd  # noqa: F401
+    from evc_amd.scorenet import build_score_network
+    from oracle.scorenet import Dims
+    from oracle.scorenet_spade import seeded_params
+    d = Dims(ngf=ngf, n_head_channels=head, image_size=image_size)
+    p = seeded_params(d, seed, spade_dim=spade_dim)
+    cfg = make_config(ngf, head, image_size)
+    cfg.model.spade = True
+    cfg.model.spade_dim = spade_dim
+    return build_score_network(cfg, p), d, p
+
+
+def test_spade_scorenet_against_reference_golden():
+    """SPADE-conditioned variant (reference SPADE_NCSNpp, ``model.spade: true``): integer, per-sample mixed and fractional
+    labels against the imported reference's outputs; the per-chunk gamma/beta map cache follows the cond tensor."""
+    from evc_amd.scorenet_spade import SpadeScoreNet
+    g = golden("forward_spade")
+    net, d, p = build_spade(32, 32, 32, 81, 32)
+    assert isinstance(net, SpadeScoreNet)
+    x, cond = rnd(82, 2, 15, 32, 32).cuda(), rnd(83, 2, 6, 32, 32).cuda()
+    for key, lab in (("out_t0", [0, 0]), ("out_t990_3", [990, 3]), ("out_tm05", [-0.5, -0.5])):
+        assert rel(net(x, torch.tensor(lab), cond=cond), g[key]) < 1e-4, key
+    n_maps = len(net._maps)
+    assert n_maps == 2 * sum(m["kind"] == "res" for m in net.program) + 1       # computed once, reused by the 3 forwards
+    # another conditioning tensor: the maps are rebuilt (outputs change), and the first one gives the golden again
+    other = net(x, torch.tensor([0, 0]), cond=cond.flip(0).contiguous())
+    assert rel(other, g["out_t0"]) > 1e-2
+    assert rel(net(x, torch.tensor([0, 0]), cond=cond), g["out_t0"]) < 1e-4
+    # in-place update of the same tensor object (what a chunk loop that reuses its buffer does) is noticed too
+    c2 = cond.clone()
+    a = net(x, torch.tensor([0, 0]), cond=c2)
+    c2.copy_(cond.flip(0))
+    assert rel(net(x, torch.tensor([0, 0]), cond=c2), other.cpu().numpy()) < 1e-5 and rel(a, g["out_t0"]) < 1e-4
+    with pytest.raises(ValueError):
+        net(x, torch.tensor([0, 0]))
+
+
+def test_spade_scorenet_through_the_ddpm_sampler_matches_oracle():
+    """The SPADE network behind the same sampler API: 4 DDPM steps with injected noise against the CPU oracle."""
+    import evc_amd  # noqa: F401
+    from evc_amd import sampler as S
+    from oracle import samplers as OS, schedule as OSch, scorenet_spade as OSP
+    net, d, p = build_spade(32, 32, 32, 81, 32)
+    x, cond = rnd(84, 2, 15, 32, 32), rnd(85, 2, 6, 32, 32)
+    noises = [rnd(90 + i, 2, 15, 32, 32) for i in range(4)]
+    ref = OS.ddpm(x.clone(), lambda xx, t: OSP.forward(p, d, xx, t, cond, spade_dim=32), OSch.base_schedule(),
+                  subsample_steps=4, noise_fn=lambda i, xx: noises[i])
+    out = S.ddpm_sampler(x.cuda(), net, cond=cond.cuda(), subsample_steps=4, denoise=True, clip_before=True,
+                         final_only=True, noise_fn=lambda i, xx: noises[i])[0].cpu()
+    assert rel(out, ref.numpy()) < 2e-4
