@@ -1859,22 +1859,31 @@ static int g_no_reuse = 0;     // same: lets the harness A/B the row-reuse kerne
 static int g_no_2d = !EVC_CONV_2D;   // 2-D patch tiles off (row tiles instead); run-time option "tiles2d"
 static int g_force_tm = 0;     // tools/conv_bench.hip (same translation unit) sets this to sweep tile heights; never set in the library
 
-// bf16x6 kernel: 2 workgroups per CU (60 KB LDS each) = 512 slots, and a workgroup's speed is set by its own
-// dependency chain, not by how many share the CU, so the grid behaves like rounds of 512 equal jobs.  The choice
-// below scores every (tile height, split factor) by
-//     round efficiency x/ceil(x), x = workgroups / 512          (a 1.1-round grid wastes half the machine)
-//   * steps / (steps + 6)                                       (prologue + epilogue of a workgroup ~ 6 K-steps)
-//   * 0.75 for 64-pixel tiles of multi-tap filters              (twice the weight traffic per MFMA; measured ~0.8)
-//   / (1 + c * splits / K)                                      (slab write + combine read: 8 B per output element
-//                                                                and split against 2*K FLOP; c = 40 while the slabs
-//                                                                stay in L2 / MALL, 300 beyond 192 MB)
-// and was checked against a measured sweep on MI355X (tools/conv_bench.hip, mode 2): it picks
-// the measured optimum or a configuration within a few percent of it for every layer shape of the network at
-// B = 4, 5 and 9 (e.g. 64x64 192->192, B=9: splits 3 instead of 2, 139 -> 161 TFLOP/s; 32x32 384->384: 4 -> 3,
-// 141 -> 171).
+// Tile height and split-K factor of the split-arithmetic kernels: 2 workgroups per CU = 512 slots.  Every candidate
+// (tile height, split factor) gets an estimated time from the grid model inside split_tile_cfg() -- rounds of 512
+// workgroups x (K-steps + fixed cost per workgroup) x co-residency factor -- times
+//     1 / 0.75 for 64-pixel tiles of multi-tap filters            (twice the weight traffic per MFMA; measured ~0.8)
+//     (1 + c * splits / K)                                        (slab write + combine read: 8 B per output element
+//                                                                  and split against 2*K FLOP; c = 40 while the slabs
+//                                                                  stay in L2 / MALL, 300 beyond 192 MB)
+// and the smallest wins.  Checked against measured sweeps on MI355X (tools/conv_bench.hip, mode 2; bf16x6: round 1,
+// DESIGN.md section 3; f16x3: profiles/r02_conv_sweep_f16x3.log and r02_conv_sweep_f16x3_after.log): the pick is the
+// measured optimum or within a few percent of it for the layer shapes of the network at B = 9.
 static void split_tile_cfg(const evc_conv_args* a, long long M, long long ntile, int nsteps, TileCfg& c, bool rr_ok) {
     const double K = (double)a->KH * a->KW * (a->C0 + a->C1);
-    double best = -1.0;
+    // Time model of a grid of n equal workgroups of `sps` K-steps each, in units of one workgroup's K-step when it has
+    // its CU to itself:  (sps + E) per workgroup (E = prologue + epilogue), x F2 when two share a CU, in rounds of 512
+    // (2 per CU); a last partial round of <= 256 workgroups runs one per CU.  bf16x6: E = 6, F2 = 1 (a workgroup's speed is
+    // set by its own dependency chain -- the round-1 sweep); f16x3: E = 20, F2 = 1.5, fitted to the round-2 sweep
+    // (profiles/r02_conv_sweep_f16x3.log: its K-steps are twice as fast, so the fixed costs weigh twice as much, and two
+    // workgroups on a CU do slow each other down: 32x32 384->384 at 1 / 2 / 3 / 7 splits = 195 / 255 / 327 / 292 TFLOP/s).
+    const bool f16 = a->arith == EVC_ARITH_F16X3 && rr_ok;       // fitted on the 3x3 row-reuse kernel; 1x1 filters keep the old fit
+    const double E = f16 ? 20.0 : 6.0, F2 = f16 ? 1.5 : 1.0;
+    const auto grid_time = [&](long long n, double sps) {
+        const long long R = n / 512, rem = n - R * 512;
+        return (sps + E) * ((double)R * F2 + (rem == 0 ? 0.0 : (rem <= 256 && f16 ? 1.0 : F2)));
+    };
+    double best = 1e300;
     int best_tm = 2, best_s = 1;
     c.tail_first = 0; c.tail_tiles = 0; c.tail_splits = 1; c.tail_sps = 0;
     for (int tm = 2; tm >= 1; --tm) {
@@ -1882,13 +1891,17 @@ static void split_tile_cfg(const evc_conv_args* a, long long M, long long ntile,
         const long long tiles = ((M + 64 * tm - 1) / (64 * tm)) * ntile;
         const int smax = a->splits > 0 ? a->splits : (nsteps / 4 < 1 ? 1 : (nsteps / 4 > 32 ? 32 : nsteps / 4));
         for (int s = a->splits > 0 ? a->splits : 1; s <= smax; ++s) {
-            const double x = (double)tiles * s / 512.0;
-            const double eff = x <= 1.0 ? x : x / (double)(long long)(x + 0.999999);
             const double sps = (double)((nsteps + s - 1) / s);
             const double slab_mb = (double)s * (double)M * a->Co * 4.0 / 1e6;
+            // slab write + combine read: 8 B per output element and split against 2*K FLOP (c = 40 while the slabs stay
+            // in L2 / MALL, 300 beyond 192 MB)
             const double pen = s > 1 ? 1.0 + (slab_mb > 192.0 ? 300.0 : 40.0) * s / K : 1.0;
-            const double score = eff * sps / (sps + 6.0) * (tm == 1 && a->KH * a->KW > 1 ? 0.75 : 1.0) / pen;
-            if (score > best * 1.0001) { best = score; best_tm = tm; best_s = s; }
+            // 64-pixel tiles of multi-tap filters: twice the weight traffic per MFMA (measured ~0.8); a 64-pixel tile's
+            // K-step is half the work of a 128-pixel one
+            // (0.55 where the 128-pixel tiles would run on the row-reuse kernel, which 64-pixel tiles cannot)
+            const double tmf = tm == 1 ? (a->KH * a->KW > 1 ? 0.5 / (rr_ok ? 0.55 : 0.75) : 0.5) : 1.0;
+            const double t = grid_time(tiles * s, sps) * pen * tmf;
+            if (t < best * 0.9999) { best = t; best_tm = tm; best_s = s; }
         }
     }
     c.tm = best_tm;
@@ -1898,7 +1911,7 @@ static void split_tile_cfg(const evc_conv_args* a, long long M, long long ntile,
     // K-split TAIL (row-reuse kernel, 128-pixel tiles, caller did not fix the split): R >= 1 full rounds of unsplit tiles,
     // then the tiles of the partial round split `ts` ways so that they fill the machine once more with short jobs --
     // instead of splitting EVERY tile (slabs + combine for the whole output) or leaving a mostly idle last round.
-    // Same time model as above: rounds x (steps + 6) x slab penalty (the tail's slabs only cover the tail's rows).
+    // Same time model (the tail's slabs only cover the tail's rows).
     if (rr_ok && g_tail_split && a->splits <= 0 && !g_force_tm && M % 128 == 0) {
         const long long tm_all = M / 128, wgs = tm_all * ntile;
         const long long R = wgs / 512;
@@ -1911,12 +1924,9 @@ static void split_tile_cfg(const evc_conv_args* a, long long M, long long ntile,
                 int sps = (nsteps + ts - 1) / ts;
                 sps = (sps + 2) / 3 * 3;
                 ts = (nsteps + sps - 1) / sps;
-                const double x_t = (double)(tail_m * ntile * ts) / 512.0;
-                const double t_tail = (double)R * (nsteps + 6.0) +
-                                      (double)(long long)(x_t + 0.999999) * (sps + 6.0) * (1.0 + 40.0 * ts / K);
-                const double work = (double)wgs / 512.0 * nsteps;
-                const double score_tail = work / t_tail;
-                if (ts >= 2 && score_tail > best * 1.02) {
+                const double t_tail = grid_time(main_m * ntile, (double)nsteps) +
+                                      grid_time(tail_m * ntile * ts, (double)sps) * (1.0 + 40.0 * ts / K);
+                if (ts >= 2 && t_tail < best * 0.98) {
                     c.tm = 2; c.bm = 128; c.tiles = wgs; c.splits = 1;
                     c.tail_first = (int)main_m; c.tail_tiles = (int)tail_m; c.tail_splits = ts; c.tail_sps = sps;
                 }
