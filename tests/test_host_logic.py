@@ -95,6 +95,26 @@ def test_conv_dispatch_queries_without_gpu():
     assert q(1, 128, 128, 24, 192, 3, 3) == 0                      # invalid (channels % 16) -> never fused
 
 
+def test_conv_k_split_tail_plan_without_gpu():
+    """Grids of 1.x / 2.x rounds (BASELINE configs[1], B=9): only the tiles of the last partial round get split-K slabs
+    (workspace = tail splits x tail rows x Co floats), exact multiples of a round and explicit split factors get none,
+    and the switch turns the plan off."""
+    f16 = lib.ARITH_F16X3
+    ws = lib.conv_workspace_bytes
+    # 128x128 192->192: 1152 tiles = 2 rounds + 128 tiles, split 4 ways (K = 1728: 27 K-steps each)
+    assert ws(9, 128, 128, 192, 192, 3, 3, arith=f16) == 4 * 128 * 128 * 192 * 4
+    # 64x64 384->384: 288 pixel tiles x 2 channel tiles = 1 round + 32 pixel tiles, split 8 ways
+    assert ws(9, 64, 64, 384, 384, 3, 3, arith=f16) == 8 * 32 * 128 * 384 * 4
+    assert ws(8, 128, 128, 192, 192, 3, 3, arith=f16) == 0                      # exactly 2 rounds
+    assert ws(9, 128, 128, 192, 192, 3, 3, splits=2, arith=f16) == 2 * 9 * 128 * 128 * 192 * 4
+    assert lib.conv_fused_stats_splits(9, 128, 128, 192, 192, 3, 3, arith=f16) == 128 * 128 // 64
+    lib.conv_set_option("tail_split", 0)
+    try:
+        assert ws(9, 128, 128, 192, 192, 3, 3, arith=f16) == 0
+    finally:
+        lib.conv_set_option("tail_split", 1)
+
+
 def test_container_roundtrip_and_corruption():
     from evc_amd import container
     rng = np.random.default_rng(0)
