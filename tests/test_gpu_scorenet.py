@@ -326,3 +326,17 @@ def test_spade_scorenet_through_the_ddpm_sampler_matches_oracle():
     out = S.ddpm_sampler(x.cuda(), net, cond=cond.cuda(), subsample_steps=4, denoise=True, clip_before=True,
                          final_only=True, noise_fn=lambda i, xx: noises[i])[0].cpu()
     assert rel(out, ref.numpy()) < 2e-4
+
+
+def test_spade_scorenet_full_size_against_oracle():
+    """The SPADE variant at the full configuration (ngf 192, 128x128, spade_dim 128; 5 resolution levels, every tile /
+    split choice of the real layer shapes) against the CPU oracle -- itself pinned to the reference at reduced size --
+    on the same seeded weights, mixed labels in one batch."""
+    torch.set_num_threads(16)
+    from oracle import scorenet_spade as OSP
+    net, d, p = build_spade(192, 192, 128, 91, 128)
+    x, cond = rnd(92, 2, 15, 128, 128), rnd(93, 2, 6, 128, 128)
+    labels = torch.tensor([700, 20])
+    ref = OSP.forward(p, d, x, labels, cond, spade_dim=128)
+    out = net(x.cuda(), labels, cond=cond.cuda())
+    assert rel(out, ref.numpy()) < 2e-4
