@@ -22,7 +22,18 @@ def diffusion_param_shapes(config, prefix="unet.all_modules."):
     d = dims_from_config(config)
     out = []
     t = 4 * d.ngf
-    for i, m in enumerate(build_program(d)):
+    spade = bool(getattr(config.model, "spade", False))      # SPADE_NCSNpp (ncsnpp_more.py:396-586): per-act-norm gamma / beta convs
+    sdim = getattr(config.model, "spade_dim", 128)
+    cond_ch = d.channels * d.num_frames_cond
+
+    def spade_shapes(n, ch):
+        return [(n + ".mlp_shared.0.weight", (sdim, cond_ch, 3, 3)), (n + ".mlp_shared.0.bias", (sdim,)),
+                (n + ".mlp_gamma.weight", (ch, sdim, 3, 3)), (n + ".mlp_gamma.bias", (ch,)),
+                (n + ".mlp_beta.weight", (ch, sdim, 3, 3)), (n + ".mlp_beta.bias", (ch,))]
+    program = build_program(d)
+    if spade:
+        program[2]["cin"] = d.channels * d.num_frames
+    for i, m in enumerate(program):
         n = prefix + str(i)
         k = m["kind"]
         if k == "linear":
@@ -32,10 +43,12 @@ def diffusion_param_shapes(config, prefix="unet.all_modules."):
             out += [(n + ".weight", (m["cout"], m["cin"], 3, 3)), (n + ".bias", (m["cout"],))]
         elif k == "res":
             ci, co = m["cin"], m["cout"]
-            out += [(n + ".actnorm0.Dense_0.weight", (2 * ci, t)), (n + ".actnorm0.Dense_0.bias", (2 * ci,)),
-                    (n + ".Conv_0.weight", (co, ci, 3, 3)), (n + ".Conv_0.bias", (co,)),
-                    (n + ".actnorm1.Dense_0.weight", (2 * co, t)), (n + ".actnorm1.Dense_0.bias", (2 * co,)),
-                    (n + ".Conv_1.weight", (co, co, 3, 3)), (n + ".Conv_1.bias", (co,))]
+            out += [(n + ".actnorm0.Dense_0.weight", (2 * ci, t)), (n + ".actnorm0.Dense_0.bias", (2 * ci,))]
+            out += spade_shapes(n + ".actnorm0.Norm_0", ci) if spade else []
+            out += [(n + ".Conv_0.weight", (co, ci, 3, 3)), (n + ".Conv_0.bias", (co,)),
+                    (n + ".actnorm1.Dense_0.weight", (2 * co, t)), (n + ".actnorm1.Dense_0.bias", (2 * co,))]
+            out += spade_shapes(n + ".actnorm1.Norm_0", co) if spade else []
+            out += [(n + ".Conv_1.weight", (co, co, 3, 3)), (n + ".Conv_1.bias", (co,))]
             if ci != co or m["up"] or m["down"]:
                 out += [(n + ".Conv_2.weight", (co, ci, 1, 1)), (n + ".Conv_2.bias", (co,))]
         elif k == "attn":
@@ -44,7 +57,8 @@ def diffusion_param_shapes(config, prefix="unet.all_modules."):
             for j in range(4):
                 out += [(n + f".NIN_{j}.W", (c, c)), (n + f".NIN_{j}.b", (c,))]
         elif k == "norm":
-            out += [(n + ".Norm_0.weight", (m["ch"],)), (n + ".Norm_0.bias", (m["ch"],))]
+            out += spade_shapes(n + ".Norm_0", m["ch"]) if spade else \
+                [(n + ".Norm_0.weight", (m["ch"],)), (n + ".Norm_0.bias", (m["ch"],))]
     return out
 
 
@@ -55,7 +69,7 @@ def diffusion_state_dict(config, seed):
         leaf = name.rsplit(".", 1)[1]
         if leaf in ("bias", "b"):
             a = 0.1 * rng.standard_normal(shape, dtype=np.float32)
-        elif "Norm_0.weight" in name:   # GroupNorm_0.weight / Norm_0.weight
+        elif name.endswith("Norm_0.weight"):   # GroupNorm_0.weight / Norm_0.weight (not Norm_0.mlp_*.weight)
             a = 1.0 + 0.1 * rng.standard_normal(shape, dtype=np.float32)
         elif leaf == "W":
             a = rng.standard_normal(shape, dtype=np.float32) / np.float32(math.sqrt(shape[0]))

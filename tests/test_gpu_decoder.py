@@ -123,3 +123,58 @@ def test_full_ddpm_chunk_psnr_against_oracle():
     a, b = ((out + 1) / 2).clamp(0, 1).double(), ((ref + 1) / 2).clamp(0, 1).double()
     psnr = 10 * torch.log10(1.0 / ((a - b) ** 2).mean())
     assert float(psnr) >= 60.0, float(psnr)
+
+
+def test_clip_decoder_with_the_spade_network_vs_oracle():
+    """The receiver loop with the SPADE-conditioned network (``model.spade: true``): the conditioning frames change
+    from chunk to chunk, so the per-chunk gamma / beta maps must be rebuilt for every generation call; generated frames
+    against the oracle sampler + oracle SPADE network on the same decoded conditioning frames and injected noise.
+    Weights come from the synthetic checkpoint generator (SPADE parameter names and order of the reference)."""
+    import evc_amd  # noqa: F401
+    from evc_amd import sampler as S, synthetic
+    from evc_amd.config import default_config
+    from evc_amd.decoder import ClipDecoder
+    from evc_amd.elic import ElicModel
+    from evc_amd.scorenet import build_score_network
+    from evc_amd.scorenet_spade import SpadeScoreNet
+    from oracle import samplers as OS, schedule as OSch, scorenet as ON, scorenet_spade as OSP
+
+    cfg = default_config(32, 32, 64, subsample=3)
+    cfg.model.spade = True
+    cfg.model.spade_dim = 32
+    d_net = ON.Dims(ngf=32, n_head_channels=32, image_size=64)
+    p = synthetic.diffusion_state_dict(cfg, 19)
+    assert [k for k, _ in OSP.param_shapes(d_net, spade_dim=32)] == list(p)      # reference state-dict order
+    net = build_score_network(cfg, p)
+    assert isinstance(net, SpadeScoreNet)
+    elic = ElicModel(synthetic.elic_state_dict(4))
+    dec = ClipDecoder(net, elic, cfg, S.get_sampler("DDPM"))
+    B, F = 2, 12
+    clips = torch.from_numpy(synthetic.make_clips(B, seed=6, frames=F, size=64).astype(np.float32) / 255)
+    mask = np.array([1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    key_strings, shape = [], None
+    for f in (0, 1):
+        enc = elic.compress(clips[:, f].cuda())
+        key_strings.append(enc["strings"])
+        shape = enc["shape"]
+    noise_log = []
+
+    def noise_fn(tag, shp):
+        tns = rnd(2000 + len(noise_log), *shp)
+        noise_log.append((tag, tns))
+        return tns.cuda()
+    out = dec.decode(mask, key_strings, shape, frames=F, noise_fn=noise_fn).cpu()
+    inits = [i for i, (tag, _) in enumerate(noise_log) if tag == "init"]
+    assert len(inits) == 2                                   # frames 2-6 and 7-11, each conditioned on the two before
+    sched = OSch.base_schedule()
+
+    def oracle_chunk(prev2, log):
+        cond = 2 * prev2.reshape(B, 6, 64, 64) - 1
+        steps = {tag: tns for tag, tns in log[1:]}
+        x = OS.ddpm(log[0][1].clone(), lambda xx, tt: OSP.forward(p, d_net, xx, tt, cond, spade_dim=32), sched,
+                    subsample_steps=3, noise_fn=lambda i, xx: steps[i])
+        return ((x[0] + 1) / 2).clamp(0, 1).reshape(B, 5, 3, 64, 64)
+    g1 = oracle_chunk(out[:, 0:2], noise_log[inits[0]:inits[1]])
+    assert float((out[:, 2:7] - g1).abs().max()) < 2e-3
+    g2 = oracle_chunk(out[:, 5:7], noise_log[inits[1]:])
+    assert float((out[:, 7:12] - g2).abs().max()) < 2e-3
