@@ -12,29 +12,41 @@ inline int grid_for(size_t n, int cap = 4096) {
 #define EVC_LAUNCH_OK() (hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH)
 
 // out[b][h][w][c] = c < C0 ? x0[b][c][h][w] : c < C0+C1 ? x1[b][c-C0][h][w] : 0.
-// Reads are coalesced along w per plane (lanes walk pixels), writes are Cpad*4-byte rows per lane.
+// One thread = one pixel, all of its Cpad channels: every plane is read coalesced along w (lanes walk pixels) and the
+// pixel's row is written as float4s, so a wave writes 64 * Cpad * 4 contiguous bytes (round 1 wrote one float per lane
+// at a Cpad * 4-byte stride: 1.2 TB/s).
 __global__ void pack_nchw_to_nhwc_kernel(const float* __restrict__ x0, int C0, const float* __restrict__ x1, int C1,
-                                         float* __restrict__ out, int Cpad, int HW, size_t total) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int p = (int)(i % HW);
-        const size_t r = i / HW;
-        const int c = (int)(r % Cpad);
-        const int b = (int)(r / Cpad);
-        float v = 0.f;
-        if (c < C0) v = x0[((size_t)b * C0 + c) * HW + p];
-        else if (c < C0 + C1) v = x1[((size_t)b * C1 + (c - C0)) * HW + p];
-        out[((size_t)b * HW + p) * Cpad + c] = v;
+                                         float* __restrict__ out, int Cpad, int HW, size_t npix) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / HW;
+        const size_t p = i - b * HW;
+        const float* s0 = x0 + b * C0 * HW + p;
+        const float* s1 = C1 > 0 ? x1 + b * C1 * HW + p : x0;
+        const auto ld = [&](int c) { return c < C0 ? s0[(size_t)c * HW] : (c < C0 + C1 ? s1[(size_t)(c - C0) * HW] : 0.f); };
+        float* o = out + i * Cpad;
+        int c = 0;
+        if ((Cpad & 3) == 0)
+            for (; c + 4 <= Cpad; c += 4) *reinterpret_cast<float4*>(o + c) = make_float4(ld(c), ld(c + 1), ld(c + 2), ld(c + 3));
+        for (; c < Cpad; ++c) o[c] = ld(c);
     }
 }
 
+// out[b][c][h][w] = in[b][h][w][c] (row stride ld): one thread = one pixel, its C values read as one contiguous row,
+// every output plane written coalesced along w.
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int ld, float* __restrict__ out, int C, int HW,
-                                    size_t total) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int p = (int)(i % HW);
-        const size_t r = i / HW;
-        const int c = (int)(r % C);
-        const int b = (int)(r / C);
-        out[i] = in[((size_t)b * HW + p) * ld + c];
+                                    size_t npix) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / HW;
+        const size_t p = i - b * HW;
+        const float* r = in + i * ld;
+        float* o = out + b * C * HW + p;
+        int c = 0;
+        if ((ld & 3) == 0)
+            for (; c + 4 <= C; c += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(r + c);
+                o[(size_t)c * HW] = v.x; o[(size_t)(c + 1) * HW] = v.y; o[(size_t)(c + 2) * HW] = v.z; o[(size_t)(c + 3) * HW] = v.w;
+            }
+        for (; c < C; ++c) o[(size_t)c * HW] = r[c];
     }
 }
 
@@ -166,17 +178,17 @@ extern "C" int evc_pack_nchw_to_nhwc_f32(const float* x0, int C0, const float* x
                                          int B, int H, int W, void* stream) {
     if (!x0 || !out || C0 <= 0 || C1 < 0 || (C1 > 0 && !x1) || Cpad < C0 + C1 || B <= 0 || H <= 0 || W <= 0)
         return EVC_EINVAL;
-    const size_t total = (size_t)B * Cpad * H * W;
-    hipLaunchKernelGGL(pack_nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x0, C0, x1,
-                       C1, out, Cpad, H * W, total);
+    const size_t npix = (size_t)B * H * W;
+    hipLaunchKernelGGL(pack_nchw_to_nhwc_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, x0, C0, x1,
+                       C1, out, Cpad, H * W, npix);
     return EVC_LAUNCH_OK();
 }
 
 extern "C" int evc_nhwc_to_nchw_f32(const float* in, int ld, float* out, int B, int C, int H, int W, void* stream) {
     if (!in || !out || C <= 0 || ld < C || B <= 0 || H <= 0 || W <= 0) return EVC_EINVAL;
-    const size_t total = (size_t)B * C * H * W;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, ld, out, C,
-                       H * W, total);
+    const size_t npix = (size_t)B * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, in, ld, out, C,
+                       H * W, npix);
     return EVC_LAUNCH_OK();
 }
 
