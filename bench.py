@@ -22,7 +22,10 @@ Rank 0 prints ONE JSON line (contract in the task statement) with these extra ob
                   PMC passes when (and only when) they were taken on the kernel source that is running
   hbm_classes  -- achieved HBM rate of the memory-bound kernel classes, HIP-event timed at the
                   benchmark's shapes
-  cpu_baseline -- the CPU oracle (a port, kind "port") timed on this box's host cores on a bounded sample
+  cpu_baseline -- the CPU oracle (a port, kind "port") timed on this box's host cores on a bounded sample (single-rank
+                  runs only: with N > 1 ranks the other ranks would sit in a collective while rank 0 measures)
+  per_rank_value / range_events -- every rank's own frames/s (load imbalance shows here), and the sticky range-event
+                  word of the fp16-split arithmetic (0 = every operand provably in range, every tensor finite)
 """
 import argparse
 import hashlib
@@ -108,12 +111,27 @@ def roofline_leg(net, clips, device):
     L.CONV_PROFILE = None
     torch.cuda.synchronize()
     net.overlap_skip = overlap
-    per = {}
+    per, kern = {}, {}
+    mode_of = lambda c: (2 if c["act_in"] == L.ACT_SILU else 1) if c["coef"] else {L.ACT_SILU: 3, L.ACT_RELU: 4}.get(c["act_in"], 0)
     for r in prof:
         v = per.setdefault((r["arith"], r["variant"]), dict(n=0, ms=0.0, flops=0.0))
+        ms = r["e0"].elapsed_time(r["e1"])
         v["n"] += 1
-        v["ms"] += r["e0"].elapsed_time(r["e1"])
+        v["ms"] += ms
         v["flops"] += r["flops"]
+        # the kernel template instance this launch runs (csrc/conv_igemm.hip dispatch: row-reuse kernel for 3x3 filters on
+        # whole-row tiles, simple-schedule kernel otherwise) -- the name rocprofv3 --kernel-trace --stats reports
+        c = r["call"]
+        np_ = {1: 3, 2: 2}.get(r["arith"])
+        if np_ is None:
+            name = f"conv_igemm_kernel<2, {r['variant']}, {mode_of(c)}>"
+        elif c["K"] == 3 and 128 % c["W"] == 0:
+            name = f"conv_split_rr_kernel<{np_}, 2, {r['variant']}, {mode_of(c)}>"
+        else:
+            name = (f"conv_splitn_kernel<2, *, {r['variant']}, {mode_of(c)}>" if np_ == 2 else
+                    f"conv_split_kernel<*, {r['variant']}, {mode_of(c)}>")
+        kv = kern.setdefault((name, r["arith"]), dict(n=0, ms=0.0, flops=0.0))
+        kv["n"] += 1; kv["ms"] += ms; kv["flops"] += r["flops"]
     dom = max(per, key=lambda k: per[k]["ms"])
     d = per[dom]
     arith, tn = dom
@@ -123,16 +141,46 @@ def roofline_leg(net, clips, device):
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     total_ms = sum(v["ms"] for v in per.values()) / reps
     total_flops = sum(v["flops"] for v in per.values()) / reps
+    # the single dominant kernel instance: frac = GFLOP per launch / average launch duration / peak, recomputable from the
+    # committed rocprofv3 --kernel-trace --stats CSV of the same forward (profiles/r03_forward_b9_kernel_stats.csv, taken
+    # with the side stream off like this leg; a split-K launch's HIP-event bracket here spans the combine kernel too)
+    (dk_name, dk_arith), dk = max(kern.items(), key=lambda kv: kv[1]["ms"])
+    dk_peak = ARITH_INFO[dk_arith][1]
+    dk_us = dk["ms"] / dk["n"] * 1e3
+    dominant = {"name": dk_name, "launches_per_forward": dk["n"] // reps, "avg_us_hip_events": round(dk_us, 2),
+                "gflop_per_launch": round(dk["flops"] / dk["n"] / 1e9, 3),
+                "tflops": round(dk["flops"] / (dk["ms"] * 1e-3) / 1e12, 1),
+                "frac": round(dk["flops"] / (dk["ms"] * 1e-3) / 1e12 / dk_peak, 4), "peak": round(dk_peak, 1)}
+    try:
+        import csv
+        meta = json.load(open(os.path.join(REPO, "profiles", "r03_forward_b9_kernel_stats.json")))
+        if meta.get("source_sha") == source_sha() and meta.get("batch") == clips:
+            base, targs = dk_name.split("<")[0], dk_name.split("<")[1].rstrip(">")
+            for row in csv.DictReader(open(os.path.join(REPO, "profiles", "r03_forward_b9_kernel_stats.csv"))):
+                if base + "<" + targs + ">" in row["Name"]:
+                    us = float(row["AverageNs"]) / 1e3
+                    dominant["avg_us_rocprof"] = round(us, 2)
+                    dominant["frac_rocprof"] = round(dominant["gflop_per_launch"] * 1e9 / (us * 1e-6) / 1e12 / dk_peak, 4)
+                    dominant["rocprof_csv"] = "profiles/r03_forward_b9_kernel_stats.csv"
+                    break
+            if meta.get("held_clock_ghz"):
+                dominant["held_clock_ghz"] = meta["held_clock_ghz"]
+                dominant["frac_at_held_clock"] = round(dominant["frac"] * 2.4 / meta["held_clock_ghz"], 4)
+        else:
+            dominant["rocprof_note"] = (f"profiles/r03_forward_b9_kernel_stats.csv was taken on source "
+                                        f"{meta.get('source_sha')} at B={meta.get('batch')}: not quoted")
+    except Exception:
+        pass
     traffic, prov = None, "no rocprofv3 PMC profile committed for this kernel source"
     try:       # HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, only if taken on THIS source
-        pmc = json.load(open(os.path.join(REPO, "profiles", f"r02_conv_{name}_pmc.json")))
+        pmc = json.load(open(os.path.join(REPO, "profiles", f"r03_conv_{name}_pmc.json")))
         if pmc.get("source_sha") != source_sha():
-            prov = f"profiles/r02_conv_{name}_pmc.json is stale (taken on source {pmc.get('source_sha')}): not reported"
-        elif clips != pmc.get("batch") or pmc.get("kernel") != kname:
-            prov = f"profiles/r02_conv_{name}_pmc.json covers {pmc.get('kernel')} at B={pmc.get('batch')}"
+            prov = f"profiles/r03_conv_{name}_pmc.json is stale (taken on source {pmc.get('source_sha')}): not reported"
+        elif clips != pmc.get("batch"):
+            prov = f"profiles/r03_conv_{name}_pmc.json covers {pmc.get('kernel')} at B={pmc.get('batch')}"
         else:
             traffic = pmc["hbm_bytes_per_launch"]
-            prov = f"profiles/r02_conv_{name}_pmc.json, source {pmc['source_sha']}, FETCH_SIZE x2 + WRITE_SIZE"
+            prov = f"profiles/r03_conv_{name}_pmc.json, source {pmc['source_sha']}, FETCH_SIZE x2 + WRITE_SIZE"
     except Exception:
         pass
     by_family = {f"{ARITH_INFO[a][0]}<TN={t}>": {"launches_per_forward": v["n"] // reps,
@@ -147,7 +195,9 @@ def roofline_leg(net, clips, device):
             "achieved_over_f32_mfma_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 3),
             "conv_ms_per_forward": round(total_ms, 3),
             "all_conv_tflops": round(total_flops / (total_ms * 1e-3) / 1e12, 2),
-            "families": by_family, "batch": clips}
+            "dominant_kernel": dominant, "families": by_family, "batch": clips,
+            "overlap_note": "launch durations measured with the res-block side stream OFF (launches one after another); the "
+                            "timed region runs with it on"}
 
 
 def hbm_classes_leg(clips, device):
@@ -369,8 +419,11 @@ def main():
     for _ in range(a.steps):
         frames = step()
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0            # this rank's own time, before it waits for the others
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
+    per_rank = [round(a.clips * 30 * a.steps / t, 3) for t in D.gather_over_ranks(own_elapsed, device)]
+    events = int(D.sum_over_ranks(L.range_events(), device))
     assert frames.shape == (a.clips, 30, 3, 128, 128) and bool(torch.isfinite(frames).all())
     seen = int(D.sum_over_ranks(1, device))
 
@@ -405,16 +458,20 @@ def main():
                       "parallelism": f"clip-sharded dp{world}, no data-path collective; {a.groups} concurrent clip "
                                      f"group(s) per GPU",
                       "weights": "seeded random, reference architecture (262.1M + ELIC)"},
+           "per_rank_value": per_rank, "range_events": events,
            "whole_path_tflops_per_gpu": round(flop_per_step_gpu * a.steps / elapsed / 1e12, 2),
            "elic_keyframe_decode_ms_per_step": round(elic_ms, 1)}
     if rank == 0:
         progress(f"timed region: {elapsed:.2f} s for {a.steps} step(s) -> {value:.2f} frames/s; roofline + HBM probes")
         out["roofline"] = roofline_leg(net, a.clips, device)
         out["hbm_classes"] = hbm_classes_leg(a.clips, device)
-        out["cpu_baseline"] = None if a.no_cpu_baseline else cpu_baseline_leg(sd_d, sd_e, a.cpu_baseline_seconds)
-    D.barrier()
-    if rank == 0:
+        # the CPU baseline runs at N = 1 only: with more ranks the others would wait in a collective for minutes (under
+        # torchrun OMP_NUM_THREADS=1 makes it slower still) while the result line is already known
+        out["cpu_baseline"] = None if (a.no_cpu_baseline or world > 1) else cpu_baseline_leg(sd_d, sd_e, a.cpu_baseline_seconds)
+        if world > 1:
+            out["cpu_baseline_note"] = "measured by the single-rank run only (rank 0 at N = 1)"
         print(json.dumps(out), flush=True)
+    D.barrier()
 
 
 if __name__ == "__main__":

@@ -187,11 +187,12 @@ typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float pow2_scale_for(float bound_sq_bits_as_float, int target_exp) {
     const float b = sqrtf(bound_sq_bits_as_float);
-    return (b > 0.f && b < 3.0e38f) ? ldexpf(1.0f, target_exp - ilogbf(b)) : 1.0f;
+    if (!(b < 3.0e38f)) return __builtin_nanf("");      // non-finite tensor (NaN pattern from the bound kernels): NaN out
+    return b > 0.f ? ldexpf(1.0f, target_exp - ilogbf(b)) : 1.0f;
 }
 
+// the operands are scaled from true element bounds (<= 2^10), so nothing can overflow and nothing is clamped
 __device__ __forceinline__ void split2h(float v, _Float16& a, _Float16& b) {
-    v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
     a = (_Float16)v;
     b = (_Float16)(v - (float)a);
 }

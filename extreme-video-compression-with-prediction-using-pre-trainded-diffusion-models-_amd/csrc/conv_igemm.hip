@@ -38,73 +38,21 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #define EVC_CONV_TAIL 1        // row-reuse kernel, unsplit grids of 1.x / 2.x rounds: the tiles of the last partial round are split along K
                                // so that they fill the machine once more with short jobs (0 = off, for A/B; run-time option "tail_split")
 #endif
-#ifndef EVC_CONV_ABLATE
-#define EVC_CONV_ABLATE 0      // DIAGNOSTIC ONLY (wrong results): bit 0 = skip the weight DMA, bit 1 = skip the activation path,
-                               // bit 2 = activation loads kept but no transform / split / LDS store, bit 3 = activation loads from cache-hot addresses
-#endif
 #ifndef EVC_CONV_TM1
 #define EVC_CONV_TM1 1         // f32 kernel: grids with < 64 tiles of 128 pixels use 64-pixel tiles (0 disables, for A/B)
 #endif
 #ifndef EVC_SPLIT_WIDE_TILES
-#define EVC_SPLIT_WIDE_TILES 1
-#endif
-#ifndef EVC_SPLIT_XCD_REMAP
-#define EVC_SPLIT_XCD_REMAP 0     // XCD-contiguous pixel tiles: measured neutral (+-2 %) on MI355X, kept as an option
+#define EVC_SPLIT_WIDE_TILES 1 // 256-pixel / 8-wave form of the row-reuse kernel on grids of whole rounds (run-time option "wide_tiles")
 #endif
 #ifndef EVC_SPLIT_INTERLEAVE
-#define EVC_SPLIT_INTERLEAVE 5     // bf16x6 kernel: VALU instructions scheduled per MFMA in the second half (0 = compiler's order)
+#define EVC_SPLIT_INTERLEAVE 5 // bf16x6 pipelined kernel: VALU instructions scheduled per MFMA in the second half (0 = compiler's order)
 #endif
-#ifndef EVC_SPLIT_COUNTED_WAIT
-#define EVC_SPLIT_COUNTED_WAIT 1   // bf16x6 kernel: mid-step barrier leaves the in-flight activation loads outstanding
-#endif
-#ifndef EVC_CONV_PLAIN_DMA
-#define EVC_CONV_PLAIN_DMA 0   // 1: in plain mode the activation tile also goes global -> LDS by DMA (out-of-image lanes
-                               // read a zero page). Measured equal to register staging on MI355X; kept as an option.
-#endif
-#ifndef EVC_RR_OCC
-#define EVC_RR_OCC 2           // workgroups per CU the 4-wave row-reuse kernel is register-budgeted for
-#endif
-#ifndef EVC_RR_PIPE
-#define EVC_RR_PIPE 0          // f16x3 row-reuse kernel: 1 = software-pipelined K loop -- the LDS fragment reads of K-step t+1 are
-                               // issued before the MFMAs of step t (three weight buffers, the activation image of the next
-                               // macro-step staged during tx = 1), so no MFMA waits on LDS latency behind a barrier.
-                               // Measured on MI355X (profiles/r02_conv_bench_rr_pipe_ab.log): within +-2 % of the plain loop
-                               // on every layer shape -- with two workgroups per CU the partner wave's MFMAs already cover the
-                               // LDS latency -- so it is off (kept: correct, all conv tests pass with it).
-#endif
-#ifndef EVC_CONV_2D
-#define EVC_CONV_2D 0          // default of the run-time option "tiles2d" (evc_conv_set_option): 3x3 filters on 128-pixel tiles
-                               // as 2-D patches (conv_split_2d_kernel) instead of whole image rows.  Measured on MI355X
-                               // (profiles/r02_conv_bench_2d_ab.log, PMC in profiles/r02_conv_2d_pmc_sq.log): although it stages
-                               // half the activation pixels per MFMA it is 5-9 % SLOWER than the row form on every layer shape
-                               // (f16x3 128x128 192->192: 290 vs 316 TFLOP/s; same MFMA count, +21 % issue-stall cycles, and its
-                               // per-pixel epilogue addressing costs what the staging saves) -- off; kept selectable + tested.
-#endif
-#ifndef EVC_2D_FRAG_BARRIER
-#define EVC_2D_FRAG_BARRIER 1
-#endif
-#ifndef EVC_2D_STAGE_MID
-#define EVC_2D_STAGE_MID 0
-#endif
-#ifndef EVC_RR_BALANCE
-#define EVC_RR_BALANCE 0       // row-reuse kernel: 1 = the staging arithmetic of the next activation image is spread over two
-                               // K-steps (transform during tx = 1, split + LDS write during tx = 2); 0 = all of it in tx = 2.
-#endif
-#ifndef EVC_RR_INTERLEAVE
-#define EVC_RR_INTERLEAVE 0    // row-reuse kernel: VALU instructions scheduled behind each MFMA in the staging blocks (0 = the
-                               // compiler's order: the whole staging block between two groups of MFMAs).
-#endif
-// Both measured on MI355X for f16x3 (profiles/r02_conv_bench_rr_staging_ab.log, two interleaved rounds per build):
-// balance / interleave 2 / interleave 3 are within +-2 % of the plain order on every layer shape (128x128 192->192 B=9:
-// 307 / 303 / 298 / 303 TFLOP/s) -- where the staging VALU work sits inside a macro-step does not matter, the partner
-// wave's MFMAs cover it either way; EVC_RR_OCC = 3 spills (188 -> 168 VGPRs) and loses 20-25 % on GroupNorm+SiLU
-// layers, gains 5 % on plain ones.  Kept as switches, off.
-// (Round-1 variants that measured no gain -- producer/consumer specialised kernels, row reuse on the f32 MFMA -- live in
-//  tools/experiments/conv_variants_r01.hip.inc, outside the product translation unit.)
+// Variants that were measured and did not pay -- 2-D patch tiles, a software-pipelined row-reuse loop, staging balance /
+// interleave switches, XCD-contiguous tile order, LDS-DMA of plain activation tiles, producer / consumer specialised kernels,
+// an in-kernel ("last-arriver") split-K combine, the ablation diagnostics behind profiles/r02_conv_bench_ablation*.log --
+// live in tools/experiments/, outside this file.
 
 namespace {
-
-__device__ float g_zero_page[64];   // source of out-of-image taps for the DMA path (zero-initialised)
 
 constexpr int BM_MAX = 128;  // pixels per workgroup tile: 64 * TM (TM = 32-row MFMA tiles per wave, 1 or 2)
 constexpr int KC = 16;       // channels per K step (one 64-byte LDS row)
@@ -135,10 +83,13 @@ struct ConvK {
 // whole tensor is scaled by the power of two that brings that bound into [2^6, 2^7) before the fp16 split: nothing can
 // overflow (<= 2^7 * 8 = 1024), typical elements sit far above fp16's subnormals, and the exact inverse goes into the
 // accumulator scale.  Wave-uniform, evaluated once per kernel.
+// A bound that is not finite (the NaN pattern the bound kernels write when a moment is NaN / inf) gives a NaN scale: the
+// operands, the accumulator scale and so the whole output are NaN -- a non-finite input never becomes finite numbers.
 __device__ __forceinline__ float in_scale(const ConvK& p) {
     if (!p.in_bound) return 1.0f;
     const float b = sqrtf(__uint_as_float(*p.in_bound));
-    return (b > 0.f && b < 3.0e38f) ? ldexpf(1.0f, 6 - ilogbf(b)) : 1.0f;
+    if (!(b < 3.0e38f)) return __builtin_nanf("");
+    return b > 0.f ? ldexpf(1.0f, 6 - ilogbf(b)) : 1.0f;
 }
 
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -264,7 +215,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     constexpr int BM = 64 * TM;
     constexpr int BN = 64 * TN;
     constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
-    constexpr bool DMA_A = EVC_CONV_PLAIN_DMA && MODE == MODE_PLAIN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As = smem;                    // [2][BM][16]
     float* const Ws = smem + 2 * BM * KC;      // [2][BN][16]
@@ -309,11 +259,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
             }
         okmask[i] = mask;
         a_lds[i] = row * KC + 4 * (k4 ^ ((row >> 2) & 3));        // swizzled float offset inside an A buffer
-        if (DMA_A) {   // DMA lands lane-linear: this lane fills physical chunk k4, i.e. logical chunk k4 ^ f(row)
-            const unsigned kq = (unsigned)(k4 ^ ((row >> 2) & 3));
-            off0[i] = ((unsigned)mm * (unsigned)p.ld0 + 4u * kq) * 4u;
-            off1[i] = ((unsigned)mm * (unsigned)p.ld1 + 4u * kq) * 4u;
-        }
     }
 
     // fragment read offsets (floats): chunk c = 2*kk + half sits at position c ^ ((row >> 2) & 3); tile and
@@ -354,27 +299,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         // uniform byte delta of this (tap, chunk) relative to the output pixel's channel 0
         const int delta = (((c_ty - padH) * p.W + (c_tx - padW)) * ld + (first ? c : c - p.C0)) * 4;
         const unsigned safe = (unsigned)((first ? c : c - p.C0) + 4 * k4) * 4u;   // pixel 0: always legal
-        if (DMA_A) {
-            float* al = As + buf * BM * KC;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const bool ok = (okmask[i] >> tap) & 1u;
-                const char* g = ok ? src + ((first ? off0[i] : off1[i]) + (unsigned)delta)
-                                   : reinterpret_cast<const char*>(g_zero_page) + 16 * k4;
-                __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)(al + (wave * 16 + 64 * i) * KC), 16, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                aok[i] = (okmask[i] >> tap) & 1u;
-                const unsigned o = aok[i] ? (first ? off0[i] : off1[i]) + (unsigned)delta : safe;
-                areg[i] = *reinterpret_cast<const float4*>(src + o);
-            }
+        for (int i = 0; i < TM; ++i) {
+            aok[i] = (okmask[i] >> tap) & 1u;
+            const unsigned o = aok[i] ? (first ? off0[i] : off1[i]) + (unsigned)delta : safe;
+            areg[i] = *reinterpret_cast<const float4*>(src + o);
         }
         const float* wt = p.w + ((size_t)(tap * p.nchunk + c_chunk) * p.CoPad + n0) * KC;
         float* wl = Ws + buf * BN * KC;
 #pragma unroll
-        for (int j = 0; j < ((EVC_CONV_ABLATE & 1) ? 0 : TN); ++j)     // one wave instruction moves 16 rows (1 KiB); 4 waves x TN rounds
+        for (int j = 0; j < TN; ++j)     // one wave instruction moves 16 rows (1 KiB); 4 waves x TN rounds
             __builtin_amdgcn_global_load_lds((glb_void*)(wt + (size_t)(tid + 256 * j) * 4),
                                              (lds_void*)(wl + (wave * 16 + 64 * j) * KC), 16, 0, 0);
     };
@@ -384,7 +318,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         if (c_ty == p.KH) { c_ty = 0; ++c_chunk; }
     };
     auto store_a = [&](int buf) {
-        if (DMA_A) return;
         float* A = As + buf * BM * KC;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -416,10 +349,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
             if (HAS_COEF && c_chunk != prev_chunk) load_coefs();      // wave-uniform, once per KH*KW steps
         }
         issue_loads(buf ^ 1);
-#if EVC_CONV_ABLATE & 2
-#pragma unroll
-        for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(areg[i].x), "v"(areg[i].y), "v"(areg[i].z), "v"(areg[i].w));
-#endif
 
         const float* Ab = As + buf * BM * KC + a_rd;
         const float* Wb = Ws + buf * BN * KC + w_rd;
@@ -434,9 +363,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         for (int j = 0; j < TN; ++j) b1[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * KC + rd1);
         mfma_group<TM, TN>(acc, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
-#if !(EVC_CONV_ABLATE & 2)
         store_a(buf ^ 1);            // producer work for the next step sits among the second half of the MFMAs
-#endif
         mfma_group<TM, TN>(acc, a1, b1);
         __syncthreads();             // also drains the W DMA (vmcnt) before anyone reads the new buffers
     }
@@ -481,7 +408,8 @@ __device__ __forceinline__ void split3_bf16(const float4& v0, const float4& v1, 
 // relative (an fp32 rounding is 2^-24) PROVIDED h2 does not fall into fp16's subnormals: both operands are scaled by
 // powers of two first -- weights by the S_w that brings max|w| into [2^14, 2^15) (per tensor, found at pack time),
 // activations by S_a = 8 (this arithmetic is only used where the operand is GroupNorm-normalised, FIR-filtered or
-// otherwise O(1): |x * S_a| is clamped to 65504 so an outlier saturates instead of turning into inf - inf) -- and the
+// otherwise O(1); nothing is clamped: an element with |x * S_a| > 65504 turns into inf - inf = NaN in the output, and the
+// coefficient kernel reports beforehand whether one can exist, include/evc_hip.h EVC_RANGE_*) -- and the
 // accumulator is multiplied by the exact inverse 1 / (S_a S_w) in the epilogue.  Three products
 //     x*y ~ h1 g1 + h1 g2 + h2 g1              (the dropped h2 g2 is <= 2^-22 |xy|)
 // per 16-deep K slice instead of bf16x6's six: half the MFMAs, two LDS planes per operand instead of three, a cheaper
@@ -497,7 +425,9 @@ __device__ __forceinline__ void split2_f16(const float4& v0, const float4& v1, f
     const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float v = __builtin_amdgcn_fmed3f(x[j] * xscale, -65504.0f, 65504.0f);
+        // no clamp: an element beyond fp16's range becomes (inf, -inf) and NaN in the accumulator -- loud, never a silently
+        // saturated value; a NaN stays a NaN.  Whether it can happen is reported by evc_gn_coeffs_bound_f32 (EVC_RANGE_*).
+        const float v = x[j] * xscale;
         const _Float16 a = (_Float16)v;
         p1[j] = a; p2[j] = (_Float16)(v - (float)a);
     }
@@ -634,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void conv_splitn_kernel(ConvK p) {
         }
     };
     auto issue_loads = [&](int buf) {
-        if (a_active && !(EVC_CONV_ABLATE & 2)) {
+        if (a_active) {
             aok = (okmask >> (c_ty * p.KW + c_tx)) & 1u;
             const unsigned o = aok ? (a_first ? off0 : off1) + (unsigned)a_delta : a_safe;
             areg[0] = *reinterpret_cast<const float4*>(a_src + o);
@@ -643,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void conv_splitn_kernel(ConvK p) {
         const char* wt = reinterpret_cast<const char*>(p.w) + w_off;
         char* wl = Ws + buf * NP * BN * RB;
 #pragma unroll
-        for (int j = 0; j < ((EVC_CONV_ABLATE & 1) ? 0 : NWD); ++j)
+        for (int j = 0; j < NWD; ++j)
             __builtin_amdgcn_global_load_lds((glb_void*)(wt + wsrc[j]), (lds_void*)(wl + wdst[j]), 16, 0, 0);
     };
     auto advance = [&]() -> bool {          // true when the cursor moved to a new channel chunk
@@ -653,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void conv_splitn_kernel(ConvK p) {
         return false;
     };
     auto store_a = [&](int buf) {
-        if (!a_active || (EVC_CONV_ABLATE & 2)) return;
+        if (!a_active) return;
         vec pl[NP];
         SP::split(transform<MODE>(areg[0], ca[0], cs[0], aok), transform<MODE>(areg[1], ca[1], cs[1], aok), xscale, pl);
         char* A = As + buf * NP * BM * RB + a_lds;
@@ -743,20 +673,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
 
-    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD a CONTIGUOUS range of
-    // pixel tiles, so the halo rows neighbouring tiles share are fetched into one L2 instead of eight (bijective
-    // for any tile count: XCD x owns q + (x < r) tiles starting at x*q + min(x, r)).
-#if EVC_SPLIT_XCD_REMAP
-    int mtile;
-    {
-        const int nwg = gridDim.x, x = blockIdx.x & 7, i = blockIdx.x >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        mtile = x * q + min(x, r) + i;
-    }
-#else
-    const int mtile = blockIdx.x;
-#endif
-    const int m0 = mtile * BM;
+    const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int split = blockIdx.z;
     const int s_begin = split * p.steps_per_split;
@@ -839,23 +756,18 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
         }
     };
     auto load_a = [&]() {                                              // activation loads of the step L points at
-        if (a_active && !(EVC_CONV_ABLATE & 2)) {
+        if (a_active) {
             aok = (okmask >> (l_ty * p.KW + l_tx)) & 1u;
             const unsigned o = aok ? (a_first ? off0 : off1) + (unsigned)a_delta : a_safe;
-#if EVC_CONV_ABLATE & 8     // diagnostic: no global loads, the staging arithmetic still runs on laundered registers
-            asm volatile("" : "+v"(areg[0].x), "+v"(areg[0].y), "+v"(areg[0].z), "+v"(areg[0].w));
-            asm volatile("" : "+v"(areg[1].x), "+v"(areg[1].y), "+v"(areg[1].z), "+v"(areg[1].w) : "v"(o));
-#else
             areg[0] = *reinterpret_cast<const float4*>(a_src + o);
             areg[1] = *reinterpret_cast<const float4*>(a_src + o + 16);
-#endif
         }
     };
     auto dma_w = [&](int buf) {                                        // weight slab of the step W points at
         const char* wt = reinterpret_cast<const char*>(p.w) + w_off;
         char* wl = Ws + buf * 3 * BN * RB;
 #pragma unroll
-        for (int j = 0; j < ((EVC_CONV_ABLATE & 1) ? 0 : NWD); ++j)
+        for (int j = 0; j < NWD; ++j)
             __builtin_amdgcn_global_load_lds((glb_void*)(wt + wsrc[j]), (lds_void*)(wl + wdst[j]), 16, 0, 0);
     };
     auto advance_w = [&]() {
@@ -871,14 +783,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
         if (l_ty == p.KH) { l_ty = 0; ++l_chunk; chunk_setup(); load_coefs(); }
     };
     auto store_a = [&](int buf) {
-        if (!a_active || (EVC_CONV_ABLATE & 2)) return;
+        if (!a_active) return;
         bf16x8 p1, p2, p3;
-#if EVC_CONV_ABLATE & 4     // diagnostic: loads kept, no transform / split (raw bits to the three planes)
-        union { float4 f[2]; bf16x8 h[2]; } raw; raw.f[0] = areg[0]; raw.f[1] = areg[1];
-        p1 = raw.h[0]; p2 = raw.h[1]; p3 = raw.h[0];
-#else
         split3_bf16(transform<MODE>(areg[0], ca[0], cs[0], aok), transform<MODE>(areg[1], ca[1], cs[1], aok), p1, p2, p3);
-#endif
         char* A = As + buf * 3 * BM * RB + a_lds;
         *reinterpret_cast<bf16x8*>(A) = p1;
         *reinterpret_cast<bf16x8*>(A + BM * RB) = p2;
@@ -936,14 +843,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
         // activation loads of step t + 2 (issued at the end of the previous second half, consumed by store_a
         // below): wait for everything older -- the weight DMA into nxt -- but leave those two in flight.
         // (__syncthreads would drain them too: a false dependency of ~one memory latency per K-step.)
-#if EVC_SPLIT_COUNTED_WAIT
         __builtin_amdgcn_sched_barrier(0);          // the 18 MFMAs above stay above (they are not memory operations)
-        if (a_active && !(EVC_CONV_ABLATE & 2)) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (a_active) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-#else
-        __syncthreads();
-#endif
         // ---- second half (one basic block): fill `cur` with step t + 2, prefetch a2 / b0 of step t + 1 from `nxt`;
         // the staging arithmetic (transform + split) is spread over the gaps of the 18 MFMAs ----
         dma_w(cur);
@@ -993,7 +896,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvK p) {
 // weight slab is shared by twice the MFMAs (weight DMA per MFMA halved; it costs ~12 % at WM = 2); used for grids
 // that still offer >= 2 rounds of 256-pixel tiles.
 template <int NP, int WM, int TN, int MODE>
-__global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split_rr_kernel(ConvK p) {
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kernel(ConvK p) {
     typedef Split<NP> SP;
     typedef typename SP::vec vec;
     constexpr int TM = 2;
@@ -1004,15 +907,11 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
     constexpr int NPIECE = NP * 2 * TN;                         // weight DMA pieces of 1 KiB per K-step
     constexpr int NWD = WM == 2 ? (NPIECE + 3) / 4 : TN;        // WM = 4: waves 0..2*NP-1 move TN pieces each
     constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
-    constexpr bool PIPE = NP == 2 && EVC_RR_PIPE;     // software-pipelined K loop (f16x3 only: bf16x6 would not fit 2 per CU)
-    // (A ring of three weight slabs DMA'd two K-steps ahead with counted vmcnt waits at every barrier -- the plain
-    // __syncthreads() carries vmcnt(0) and so waits for the slab queued at the top of the same step -- was A/B-tested and
-    // gave nothing: profiles/r02_conv_bench_rr_deep_ab.log, patch in tools/experiments/conv_rr_deep_r02.patch.)
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     const int SR = (BM / p.W) * (p.W + 2);            // staged rows: every image row of the tile + 2 halo pixels
     const int APL = SR * RB;                          // bytes per activation plane
     char* const As = smem_b;                          // [2][NP][SR][32 B]
-    char* const Ws = smem_b + 2 * NP * APL;           // [2 (PIPE: 3)][NP][BN][32 B]
+    char* const Ws = smem_b + 2 * NP * APL;           // [2][NP][BN][32 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1020,20 +919,10 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
 
-#if EVC_SPLIT_XCD_REMAP      // XCD x owns a contiguous range of pixel tiles (bijective for any tile count)
-    int mtile;
-    {
-        const int nwg = gridDim.x, x = blockIdx.x & 7, i = blockIdx.x >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        mtile = x * q + min(x, r) + i;
-    }
-#else
-    const int mtile = blockIdx.x;
-#endif
     // K-split tail (ConvK::tail_*): blockIdx.x beyond the unsplit tiles enumerates (tile, split) pairs of the last tiles
     const bool tail = WM == 2 && (int)blockIdx.x >= p.tail_first;
     const int tq = tail ? ((int)blockIdx.x - p.tail_first) / p.tail_splits : 0;
-    const int m0 = (tail ? p.tail_first + tq : mtile) * BM;
+    const int m0 = (tail ? p.tail_first + tq : (int)blockIdx.x) * BM;
     const int n0 = blockIdx.y * BN;
     const int split = tail ? (int)blockIdx.x - p.tail_first - tq * p.tail_splits : (int)blockIdx.z;
     const int sps = tail ? p.tail_sps : p.steps_per_split;                      // multiple of 3 (host)
@@ -1120,10 +1009,8 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
         }
     };
     auto load_a = [&]() {
-        if (EVC_CONV_ABLATE & 2) return;          // diagnostic build: no activation path
         aok = (okrow >> l_ty) & 1u;
-        unsigned o = aok ? (a_first ? off0 : off1) + (unsigned)a_delta : a_safe;
-        if (EVC_CONV_ABLATE & 8) o = a_safe;      // diagnostic build: every activation load hits the same cache lines
+        const unsigned o = aok ? (a_first ? off0 : off1) + (unsigned)a_delta : a_safe;
         areg[0] = *reinterpret_cast<const float4*>(a_src + o);
         areg[1] = *reinterpret_cast<const float4*>(a_src + o + 16);
     };
@@ -1136,7 +1023,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
         char* wl = Ws + wb * NP * BN * RB;
         if (w_active) {
 #pragma unroll
-            for (int j = 0; j < ((EVC_CONV_ABLATE & 1) ? 0 : NWD); ++j)
+            for (int j = 0; j < NWD; ++j)
                 __builtin_amdgcn_global_load_lds((glb_void*)(wt + wsrc[j]), (lds_void*)(wl + wdst[j]), 16, 0, 0);
         }
     };
@@ -1146,20 +1033,9 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
         if (w_ty == 3) { w_ty = 0; w_off += w_wrap; }
     };
     const float xscale = F16_ACT_SCALE * in_scale(p);     // used by the fp16 split only
-    float4 treg[2];                                  // transformed activations between tx = 1 and tx = 2 (EVC_RR_BALANCE)
-    auto transform_a = [&]() {
-        if (EVC_CONV_ABLATE & 2) return;
-        if (EVC_CONV_ABLATE & 4) {                // diagnostic build: loads waited for, no transform / split / LDS write
-            asm volatile("" :: "v"(areg[0].x), "v"(areg[0].w), "v"(areg[1].x), "v"(areg[1].w));
-            return;
-        }
-        treg[0] = transform<MODE>(areg[0], ca[0], cs[0], aok);
-        treg[1] = transform<MODE>(areg[1], ca[1], cs[1], aok);
-    };
-    auto store_a = [&](int ab) {
-        if (EVC_CONV_ABLATE & (2 | 4)) return;
+    auto store_a = [&](int ab) {                          // transform + split + LDS write of the loaded activation registers
         vec pl[NP];
-        SP::split(treg[0], treg[1], xscale, pl);
+        SP::split(transform<MODE>(areg[0], ca[0], cs[0], aok), transform<MODE>(areg[1], ca[1], cs[1], aok), xscale, pl);
         char* A = As + ab * NP * APL + a_lds;
 #pragma unroll
         for (int q = 0; q < NP; ++q) *reinterpret_cast<vec*>(A + q * APL) = pl[q];
@@ -1177,456 +1053,78 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? EVC_RR_OCC : 1) void conv_split
     for (int o = tid * 16; o < 2 * NP * APL; o += NT * 16) *reinterpret_cast<float4*>(As + o) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
-    if constexpr (PIPE) {
-        // ---- software-pipelined K loop.  K-step t = 3g + tx uses weight buffer tx (three buffers) and activation image
-        // g & 1.  Block t: queue the weight DMA of step t+2 (buffer (tx+2) % 3), issue the LDS fragment reads of step
-        // t+1 into a second register set, run the MFMAs of step t on fragments read one block ago; the next macro-step's
-        // activation registers are loaded in tx = 0 and transformed + split + written in tx = 1, so that tx = 2 can
-        // already read the new image.  One barrier per K-step, as before; no MFMA waits on LDS latency behind it. ----
-        auto frag_a = [&](vec (&a)[TM][NP], int ab, int tx) {
-            const char* Ab = As + ab * NP * APL;
-#pragma unroll
-            for (int q = 0; q < NP; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i][q] = *reinterpret_cast<const vec*>(Ab + q * APL + ard[i][tx]);
-        };
-        auto frag_w = [&](vec (&b)[TN][NP], int wbuf) {
-            const char* Wb = Ws + wbuf * NP * BN * RB + w_rd;
-#pragma unroll
-            for (int q = 0; q < NP; ++q)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j][q] = *reinterpret_cast<const vec*>(Wb + (q * BN + j * 32) * RB);
-        };
-        auto mfmas = [&](const vec (&a)[TM][NP], const vec (&b)[TN][NP]) {
-#pragma unroll
-            for (int t = 0; t < SP::NTERM; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = SP::mfma(a[i][SP::qa(t)], b[j][SP::qb(t)], acc[i][j]);
-        };
-        vec a0[TM][NP], b0[TN][NP];            // fragments of tx = 0: read during the previous macro-step's tx = 2
-        int wnext = 0;                         // K-step (inside this split) whose weights are DMA'd next
-        if (nmac > 0) {
-            chunk_setup();
-            load_coefs();
-            load_a();
-            dma_w(0); advance_w(); ++wnext;
-            dma_w(1); advance_w(); ++wnext;     // nst >= 3
-            transform_a();
-            store_a(0);
-        }
-        __syncthreads();
-        frag_a(a0, 0, 0);
-        frag_w(b0, 0);
-        for (int g = 0; g < nmac; ++g) {
-            const int ab = g & 1;
-            vec a1[TM][NP], b1[TN][NP], a2[TM][NP], b2[TN][NP];
-            {   // ---- tx = 0 ----
-                if (wnext < nst) { dma_w(2); advance_w(); ++wnext; }
-                __builtin_amdgcn_sched_barrier(0);      // the loads below must be issued AFTER the DMA (counted wait)
-                if (g + 1 < nmac) advance_l();
-                load_a();
-                __builtin_amdgcn_sched_barrier(0);
-                frag_a(a1, ab, 1);
-                frag_w(b1, 1);
-                mfmas(a0, b0);
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // DMA landed, activation loads fly
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            {   // ---- tx = 1: stage the next macro-step's activation image ----
-                __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): the activation registers, before this block's DMA queues behind them
-                if (wnext < nst) { dma_w(0); advance_w(); ++wnext; }
-                __builtin_amdgcn_sched_barrier(0);
-                frag_a(a2, ab, 2);
-                frag_w(b2, 2);
-                mfmas(a1, b1);
-                __builtin_amdgcn_sched_barrier(0);
-                transform_a();
-                store_a(ab ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();
-            }
-            {   // ---- tx = 2: fragments of the next macro-step's tx = 0 come from the image just written ----
-                if (wnext < nst) { dma_w(1); advance_w(); ++wnext; }
-                __builtin_amdgcn_sched_barrier(0);
-                frag_a(a0, ab ^ 1, 0);
-                frag_w(b0, 0);
-                mfmas(a2, b2);
-                __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();
-            }
-        }
-    } else {
-        if (nmac > 0) {
-            chunk_setup();
-            load_coefs();
-            load_a();
-            dma_w(0);
-            transform_a();
-            store_a(0);
-            if (1 < nst) advance_w();
-        }
-        __syncthreads();
-
-        int wb = 0, sidx = 0;        // weight buffer of the current K-step, K-step index inside this split
-    #define EVC_RR_TERMS(T0, T1)                                                                            \
-        _Pragma("unroll") for (int t = T0; t < T1; ++t)                                                     \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)  \
-                acc[i][j] = SP::mfma(a[i][SP::qa(t)], b[j][SP::qb(t)], acc[i][j]);
-    #define EVC_RR_FRAGS(TX)                                                                                \
-        vec a[TM][NP], b[TN][NP];                                                                           \
-        {                                                                                                   \
-            const char* Ab = As + ab * NP * APL;                                                            \
-            const char* Wb = Ws + wb * NP * BN * RB + w_rd;                                                 \
-            _Pragma("unroll") for (int q = 0; q < NP; ++q) {                                                \
-                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
-                    a[i][q] = *reinterpret_cast<const vec*>(Ab + q * APL + ard[i][TX]);                     \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
-                    b[j][q] = *reinterpret_cast<const vec*>(Wb + (q * BN + j * 32) * RB);                   \
-            }                                                                                               \
-        }
-    #define EVC_RR_NEXT_W()                                                                                 \
-        dma_w(wb ^ 1);                              /* weights of K-step sidx + 1 */                        \
-        if (sidx + 2 < nst) advance_w();
-
-        for (int g = 0; g < nmac; ++g) {
-            const int ab = g & 1;
-            {   // ---- tx = 0: also start the activation loads of the next macro-step (the two youngest operations) ----
-                EVC_RR_NEXT_W()
-                __builtin_amdgcn_sched_barrier(0);          // the loads below must be issued AFTER the DMA (counted wait)
-                if (g + 1 < nmac) advance_l();
-                load_a();
-                __builtin_amdgcn_sched_barrier(0);
-                EVC_RR_FRAGS(0)
-                EVC_RR_TERMS(0, SP::NTERM)
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // weight DMA landed, loads stay in flight
-                __builtin_amdgcn_sched_barrier(0);
-                wb ^= 1; ++sidx;
-            }
-            // MFMAs of one K-step with the staging VALU work `WORK` spread behind them (EVC_RR_INTERLEAVE per MFMA)
-    #define EVC_RR_STEP_WITH(TX, WORK)                                                                      \
-            {                                                                                               \
-                EVC_RR_FRAGS(TX)                                                                            \
-                if (EVC_RR_INTERLEAVE) {                                                                    \
-                    WORK;                                                                                   \
-                    EVC_RR_TERMS(0, SP::NTERM)                                                              \
-                    __builtin_amdgcn_sched_group_barrier(0x100, NP * (TM + TN), 0);      /* fragment reads */  \
-                    _Pragma("unroll") for (int q_ = 0; q_ < SP::NTERM * TM * TN; ++q_) {                    \
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
-                        __builtin_amdgcn_sched_group_barrier(0x002, EVC_RR_INTERLEAVE, 0);                  \
-                    }                                                                                       \
-                } else {                                                                                    \
-                    EVC_RR_TERMS(0, SP::NTERM / 2)                                                          \
-                    __builtin_amdgcn_sched_barrier(0);                                                      \
-                    WORK;                                                                                   \
-                    __builtin_amdgcn_sched_barrier(0);                                                      \
-                    EVC_RR_TERMS(SP::NTERM / 2, SP::NTERM)                                                  \
-                }                                                                                           \
-            }
-            {   // ---- tx = 1 ----
-    #if EVC_RR_BALANCE
-                // the activation registers of the next macro-step (loaded during tx = 0) must have landed BEFORE this step's
-                // weight DMA is queued behind them: vmcnt counts in order, a later wait for them would drain the DMA too
-                __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0), expcnt / lgkmcnt untouched
-                EVC_RR_NEXT_W()
-                __builtin_amdgcn_sched_barrier(0);
-                EVC_RR_STEP_WITH(1, transform_a())
-                __builtin_amdgcn_sched_barrier(0);
-    #else
-                EVC_RR_NEXT_W()
-                EVC_RR_FRAGS(1)
-                EVC_RR_TERMS(0, SP::NTERM)
-    #endif
-                __syncthreads();
-                wb ^= 1; ++sidx;
-            }
-            {   // ---- tx = 2: stage the next macro-step's activation image among the MFMAs ----
-                EVC_RR_NEXT_W()
-                __builtin_amdgcn_sched_barrier(0);
-    #if EVC_RR_BALANCE
-                EVC_RR_STEP_WITH(2, store_a(ab ^ 1))
-    #else
-                EVC_RR_STEP_WITH(2, (transform_a(), store_a(ab ^ 1)))
-    #endif
-                __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();
-                wb ^= 1; ++sidx;
-            }
-    #undef EVC_RR_STEP_WITH
-        }
-    #undef EVC_RR_TERMS
-    #undef EVC_RR_FRAGS
-    #undef EVC_RR_NEXT_W
-    }
-
-#if EVC_CONV_ABLATE & 16      // diagnostic: no epilogue at run time (the accumulators stay live for the compiler)
-    if (p.M > 0) return;
-#endif
-    conv_epilogue<TM, TN, WM>(p, acc, m0, n0, split, wm, wn, l31, half, tail);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// 2-D tile form of the row-reuse convolution (3x3 filters, f16x3 / bf16x6): the 128 output pixels of a workgroup are a
-// TW x TH patch of ONE image (TW = 32 or 16 columns, TH = 128 / TW rows) instead of 128 / W whole rows, and a
-// macro-step is a whole 16-channel chunk: the (TH + 2) x (TW + 2) input patch is gathered, GroupNorm/SiLU-transformed,
-// split and written to LDS ONCE, and all NINE taps are K-steps whose A fragments are read from that image at offsets
-// shifted by ty * (TW + 2) + tx.  conv_split_rr_kernel stages every input row once per KERNEL ROW, i.e. 3 x 128 = 384
-// (+ halo) pixels per chunk for 128 outputs; here it is 6 x 34 = 204 (TW = 32) or 10 x 18 = 180 (TW = 16): about half
-// the activation loads, transform + split VALU work and LDS writes per MFMA, which the ablation
-// (profiles/r02_conv_bench_ablation.log) shows to be the largest cost beside the MFMAs themselves (f16x3, 128x128
-// 192->192: 322 TFLOP/s full, 458 without the activation path, 574 without any operand fetch).  Halo columns are real
-// neighbouring pixels here (zero only outside the image), so the whole patch is staged.
-// Same weight path (per-tap slabs by LDS-DMA, double-buffered), same wave tiling (4 waves, 64 pixels x 32*TN channels
-// each), one barrier per K-step.  The staging of chunk c+1 is spread over the K-steps of chunk c.
-template <int NP, int TN, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_split_2d_kernel(ConvK p, int ltw) {
-    typedef Split<NP> SP;
-    typedef typename SP::vec vec;
-    constexpr int TM = 2, BN = 64 * TN, RB = 32;
-    constexpr int NPIECE = NP * 2 * TN;
-    constexpr int NWD = (NPIECE + 3) / 4;
-    constexpr int NU = 2;                              // staging units (pixel, 8-channel half) per thread: 2 * 204 <= 512
-    constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
-    extern __shared__ __attribute__((aligned(16))) char smem_b[];
-    const int TW = 1 << ltw, TH = 128 >> ltw;
-    const int SW = TW + 2, SPX = SW * (TH + 2);        // staged patch: SPX pixels, rows of SW
-    const int APL = SPX * RB;
-    char* const As = smem_b;                           // [2][NP][SPX][32 B]
-    char* const Ws = smem_b + 2 * NP * APL;            // [2][NP][BN][32 B]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, half = lane >> 5;
-
-    // tile -> (image, patch origin)
-    const int ntx = p.W >> ltw, nty = p.H / TH;
-    const int tile = blockIdx.x;
-    const int b = tile / (ntx * nty);
-    const int tr = tile - b * (ntx * nty);
-    const int y0 = (tr / ntx) * TH, x0 = (tr - (tr / ntx) * ntx) << ltw;
-    const int n0 = blockIdx.y * BN;
-    const int split = blockIdx.z;
-    const int s_begin = split * p.steps_per_split;                              // multiple of 9 (host)
-    const int nst = min(p.nsteps, s_begin + p.steps_per_split) - s_begin;       // multiple of 9
-    const int nch = nst / 9;
-
-    // ---- staging units of this thread ----
-    unsigned uoff0[NU], uoff1[NU];
-    int ulds[NU];
-    bool uact[NU], uok[NU];
-#pragma unroll
-    for (int i = 0; i < NU; ++i) {
-        const int u = tid + 256 * i;
-        const int su = u >> 1, kh = u & 1;
-        uact[i] = su < SPX;
-        const int sy = su / SW, sx = su - sy * SW;
-        const int gy = y0 - 1 + sy, gx = x0 - 1 + sx;
-        uok[i] = uact[i] && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        const unsigned pix = uok[i] ? (unsigned)((b * p.H + gy) * p.W + gx) : 0u;
-        uoff0[i] = (pix * (unsigned)p.ld0 + 8u * kh) * 4u;
-        uoff1[i] = (pix * (unsigned)p.ld1 + 8u * kh) * 4u;
-        ulds[i] = su * RB + 16 * (kh ^ ((su >> 3) & 1));
-    }
-    const int kh0 = tid & 1;                           // both units of a thread stage the same channel half
-    // ---- fragment bases: pixel ml of the tile sits at staged position (ml / TW + ty) * SW + ml % TW + tx ----
-    int abase[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int ml = wm * 64 + i * 32 + l31;
-        abase[i] = (ml >> ltw) * SW + (ml & (TW - 1));
-    }
-    const int w_rd = wn * 32 * TN * RB + l31 * RB + 16 * (half ^ ((l31 >> 3) & 1));
-
-    unsigned wsrc[NWD];
-    int wdst[NWD];
-#pragma unroll
-    for (int j = 0; j < NWD; ++j) {
-        const int idx = min(wave + 4 * j, NPIECE - 1);
-        const int part = idx / (2 * TN), seg = idx - part * (2 * TN);
-        wsrc[j] = (unsigned)((part * p.CoPad + n0 + seg * 32) * RB + lane * 16);
-        wdst[j] = (part * BN + seg * 32) * RB;
-    }
-    const unsigned slab = (unsigned)NP * (unsigned)p.CoPad * RB;
-    const unsigned w_tap = (unsigned)p.nchunk * slab;
-    const unsigned w_wrap = slab - 9u * w_tap;
-
-    int l_chunk = s_begin / 9;                         // chunk whose activation patch is staged next
-    int w_tapi = 0;
-    unsigned w_off = (unsigned)l_chunk * slab;         // (tap 0, first chunk)
-    const int Ct = p.C0 + p.C1;
-    float4 areg[NU][2], ca[2], cs[2];
-    auto load_patch = [&]() {                          // coefficient + activation loads of chunk l_chunk
-        const int c = l_chunk * KC;
-        const bool first = c < p.C0;
-        const char* src = reinterpret_cast<const char*>(first ? p.src0 : p.src1);
-        const unsigned cc = (unsigned)(first ? c : c - p.C0) * 4u;
-        if (HAS_COEF) {
-            const size_t co = (size_t)b * Ct + c + 8 * kh0;
-            ca[0] = *reinterpret_cast<const float4*>(p.coef_a + co);
-            ca[1] = *reinterpret_cast<const float4*>(p.coef_a + co + 4);
-            cs[0] = *reinterpret_cast<const float4*>(p.coef_s + co);
-            cs[1] = *reinterpret_cast<const float4*>(p.coef_s + co + 4);
-        }
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const unsigned o = (first ? uoff0[i] : uoff1[i]) + cc;     // out-of-image units read pixel 0 (legal), zeroed later
-            areg[i][0] = *reinterpret_cast<const float4*>(src + o);
-            areg[i][1] = *reinterpret_cast<const float4*>(src + o + 16);
-        }
-    };
-    const float xscale = F16_ACT_SCALE * in_scale(p);
-    auto store_unit = [&](int i, int ab) {
-        if (!uact[i]) return;
-        vec pl[NP];
-        SP::split(transform<MODE>(areg[i][0], ca[0], cs[0], uok[i]), transform<MODE>(areg[i][1], ca[1], cs[1], uok[i]), xscale, pl);
-        char* A = As + ab * NP * APL + ulds[i];
-#pragma unroll
-        for (int q = 0; q < NP; ++q) *reinterpret_cast<vec*>(A + q * APL) = pl[q];
-    };
-    auto dma_w = [&](int wb) {
-        const char* wt = reinterpret_cast<const char*>(p.w) + w_off;
-        char* wl = Ws + wb * NP * BN * RB;
-#pragma unroll
-        for (int j = 0; j < NWD; ++j)
-            __builtin_amdgcn_global_load_lds((glb_void*)(wt + wsrc[j]), (lds_void*)(wl + wdst[j]), 16, 0, 0);
-    };
-    auto advance_w = [&]() {
-        ++w_tapi; w_off += w_tap;
-        if (w_tapi == 9) { w_tapi = 0; w_off += w_wrap; }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    if (nch > 0) {
-        load_patch();
+    if (nmac > 0) {
+        chunk_setup();
+        load_coefs();
+        load_a();
         dma_w(0);
-        advance_w();
-#pragma unroll
-        for (int i = 0; i < NU; ++i) store_unit(i, 0);
+        store_a(0);
+        if (1 < nst) advance_w();
     }
     __syncthreads();
 
-    int wb = 0, sidx = 0;
-    for (int g = 0; g < nch; ++g) {
-        const int ab = g & 1;
-        const char* Ab = As + ab * NP * APL;
-#pragma unroll 1
-        for (int ty = 0; ty < 3; ++ty) {
-#pragma unroll
-            for (int tx = 0; tx < 3; ++tx) {
-                const int tap = ty * 3 + tx;            // tx is a compile-time constant, ty a uniform scalar
-                if (sidx + 1 < nst) { dma_w(wb ^ 1); advance_w(); }
-                if (ty == 0 && tx == 0) {               // the next chunk's loads: the youngest vector-memory operations
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (g + 1 < nch) ++l_chunk;
-                    load_patch();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                vec a[TM][NP], bq[TN][NP];
-                {
-                    const int dsr = ty * SW + tx;
-                    const char* Wb = Ws + wb * NP * BN * RB + w_rd;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        const int sr = abase[i] + dsr;
-                        const int o = sr * RB + 16 * (half ^ ((sr >> 3) & 1));
-#pragma unroll
-                        for (int q = 0; q < NP; ++q) a[i][q] = *reinterpret_cast<const vec*>(Ab + q * APL + o);
-                    }
-#pragma unroll
-                    for (int q = 0; q < NP; ++q)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) bq[j][q] = *reinterpret_cast<const vec*>(Wb + (q * BN + j * 32) * RB);
-                }
-                // all ten fragment reads in flight before the first MFMA (left alone, the scheduler re-uses fragment
-                // registers and serialises read -> wait -> 3 MFMAs four times per K-step)
-#if EVC_2D_FRAG_BARRIER
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-                // staging of the next chunk's patch: unit 0 in the K-step of tap 4, unit 1 in that of tap 7 (the loads were
-                // issued at tap 0 and drained by the barriers of taps 1..); EVC_2D_STAGE_MID: between the MFMA halves
-                const bool st0 = ty == 1 && tx == 1, st1 = ty == 2 && tx == 1;
-#pragma unroll
-                for (int t = 0; t < SP::NTERM; ++t) {
-#if EVC_2D_STAGE_MID
-                    if (t == (SP::NTERM + 1) / 2 && tx == 1) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (st0) store_unit(0, ab ^ 1);
-                        if (st1) store_unit(1, ab ^ 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#endif
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) acc[i][j] = SP::mfma(a[i][SP::qa(t)], bq[j][SP::qb(t)], acc[i][j]);
-                }
-#if !EVC_2D_STAGE_MID
-                if (st0) { __builtin_amdgcn_sched_barrier(0); store_unit(0, ab ^ 1); }
-                if (st1) { __builtin_amdgcn_sched_barrier(0); store_unit(1, ab ^ 1); }
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-                if (ty == 0 && tx == 0) {   // weight DMA landed; the coefficient + activation loads (the youngest) stay in flight
-                    if constexpr (HAS_COEF) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                } else {
-                    __syncthreads();
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                wb ^= 1; ++sidx;
-            }
-        }
+    int wb = 0, sidx = 0;        // weight buffer of the current K-step, K-step index inside this split
+#define EVC_RR_TERMS(T0, T1)                                                                            \
+    _Pragma("unroll") for (int t = T0; t < T1; ++t)                                                     \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)  \
+            acc[i][j] = SP::mfma(a[i][SP::qa(t)], b[j][SP::qb(t)], acc[i][j]);
+#define EVC_RR_FRAGS(TX)                                                                                \
+    vec a[TM][NP], b[TN][NP];                                                                           \
+    {                                                                                                   \
+        const char* Ab = As + ab * NP * APL;                                                            \
+        const char* Wb = Ws + wb * NP * BN * RB + w_rd;                                                 \
+        _Pragma("unroll") for (int q = 0; q < NP; ++q) {                                                \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
+                a[i][q] = *reinterpret_cast<const vec*>(Ab + q * APL + ard[i][TX]);                     \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
+                b[j][q] = *reinterpret_cast<const vec*>(Wb + (q * BN + j * 32) * RB);                   \
+        }                                                                                               \
     }
+#define EVC_RR_NEXT_W()                                                                                 \
+    dma_w(wb ^ 1);                              /* weights of K-step sidx + 1 */                        \
+    if (sidx + 2 < nst) advance_w();
 
-    // ---- epilogue: acc row r of tile i is tile pixel ml = wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*half ----
-    const bool partial = p.splits > 1;
-    const float ascale = p.w_hdr ? p.w_hdr[0] / in_scale(p) : 1.0f;
-    const int cw = n0 + wn * 32 * TN + l31;
-    const int nsplit = p.HW >> 6;                      // 64-pixel runs per image
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int co = cw + j * 32;
-        if (co >= p.Co) continue;
-        const float bias = (!partial && p.bias) ? p.bias[co] : 0.f;
-        float st_sum = 0.f, st_sq = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const size_t m = (size_t)(b * p.H + y0 + (ml >> ltw)) * p.W + x0 + (ml & (TW - 1));
-                float v = acc[i][j][r] * ascale;
-                if (partial) {
-                    p.ws[((size_t)split * p.M + m) * p.Co + co] = v;
-                } else {
-                    v += bias;
-                    if (p.res) v += p.res[m * p.ld_res + co];
-                    v = act_fn(v * p.out_scale, p.act_out);
-                    p.out[m * p.ld_out + co] = v;
-                    st_sum += v; st_sq += v * v;
-                }
-            }
+    for (int g = 0; g < nmac; ++g) {
+        const int ab = g & 1;
+        {   // ---- tx = 0: also start the activation loads of the next macro-step (the two youngest operations) ----
+            EVC_RR_NEXT_W()
+            __builtin_amdgcn_sched_barrier(0);          // the loads below must be issued AFTER the DMA (counted wait)
+            if (g + 1 < nmac) advance_l();
+            load_a();
+            __builtin_amdgcn_sched_barrier(0);
+            EVC_RR_FRAGS(0)
+            EVC_RR_TERMS(0, SP::NTERM)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // weight DMA landed, loads stay in flight
+            __builtin_amdgcn_sched_barrier(0);
+            wb ^= 1; ++sidx;
         }
-        if (!partial && p.stats) {      // one writer per (64-pixel run of this wave, channel): deterministic
-            st_sum += __shfl_xor(st_sum, 32);
-            st_sq += __shfl_xor(st_sq, 32);
-            if (half == 0) {
-                float* sp = p.stats + ((size_t)(b * nsplit + tr * 2 + wm) * p.Co + co) * 2;
-                sp[0] = st_sum; sp[1] = st_sq;
-            }
+        {   // ---- tx = 1 ----
+            EVC_RR_NEXT_W()
+            EVC_RR_FRAGS(1)
+            EVC_RR_TERMS(0, SP::NTERM)
+            __syncthreads();
+            wb ^= 1; ++sidx;
+        }
+        {   // ---- tx = 2: stage the next macro-step's activation image between the two halves of the MFMAs ----
+            EVC_RR_NEXT_W()
+            __builtin_amdgcn_sched_barrier(0);
+            EVC_RR_FRAGS(2)
+            EVC_RR_TERMS(0, SP::NTERM / 2)
+            __builtin_amdgcn_sched_barrier(0);
+            store_a(ab ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            EVC_RR_TERMS(SP::NTERM / 2, SP::NTERM)
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            wb ^= 1; ++sidx;
         }
     }
+#undef EVC_RR_TERMS
+#undef EVC_RR_FRAGS
+#undef EVC_RR_NEXT_W
+
+    conv_epilogue<TM, TN, WM>(p, acc, m0, n0, split, wm, wn, l31, half, tail);
 }
 
 // out = act((sum_z ws[z] + bias + res) * scale): deterministic split-K combine.
@@ -1856,7 +1354,6 @@ struct TileCfg { int tm, tn, bm, bn; long long tiles; int splits; int reuse; int
 static int g_tail_split = EVC_CONV_TAIL;   // run-time option "tail_split"
 static int g_wide_tiles = EVC_SPLIT_WIDE_TILES;   // harness A/B switch for the 256-pixel row-reuse tiles
 static int g_no_reuse = 0;     // same: lets the harness A/B the row-reuse kernel inside one binary
-static int g_no_2d = !EVC_CONV_2D;   // 2-D patch tiles off (row tiles instead); run-time option "tiles2d"
 static int g_force_tm = 0;     // tools/conv_bench.hip (same translation unit) sets this to sweep tile heights; never set in the library
 
 // Tile height and split-K factor of the split-arithmetic kernels: 2 workgroups per CU = 512 slots.  Every candidate
@@ -1939,25 +1436,9 @@ static inline bool is_split_arith(int arith) { return arith == EVC_ARITH_BF16X6 
 static inline int arith_planes(int arith) { return arith == EVC_ARITH_F16X3 ? 2 : 3; }
 constexpr long long LDS_CAP = 160 * 1024;     // gfx950: 160 KiB per CU, one workgroup may take all of it
 
-// dynamic LDS of the row-reuse kernel: NP planes x 32 B x (2 activation images + 2 weight buffers; 3 for the software-
-// pipelined f16x3 form)
-// 2-D patch tiles (conv_split_2d_kernel): patch width for an image width, 0 = not applicable
-static int tile2d_ltw(const evc_conv_args* a) {
-    if (a->KH != 3 || a->KW != 3) return 0;
-    const int ltw = a->W >= 32 ? 5 : (a->W == 16 ? 4 : 0);
-    if (!ltw) return 0;
-    const int TW = 1 << ltw, TH = 128 >> ltw;
-    if (a->W % TW != 0 || a->H % TH != 0) return 0;
-    return ltw;
-}
-static long long tile2d_lds_bytes(int np, int ltw, int bn) {
-    const int TW = 1 << ltw, TH = 128 >> ltw;
-    return (long long)np * 32 * (2LL * (TW + 2) * (TH + 2) + 2LL * bn);
-}
-
+// dynamic LDS of the row-reuse kernel: NP planes x 32 B x (2 activation images + 2 weight buffers)
 static long long rr_lds_bytes(int np, int bm, int W, int bn) {
-    const int nwb = (np == 2 && EVC_RR_PIPE) ? 3 : 2;
-    return (long long)np * 32 * (2LL * (bm / W) * (W + 2) + (long long)nwb * bn);
+    return (long long)np * 32 * (2LL * (bm / W) * (W + 2) + 2LL * bn);
 }
 
 static TileCfg conv_tile_cfg(const evc_conv_args* a) {
@@ -1974,7 +1455,7 @@ static TileCfg conv_tile_cfg(const evc_conv_args* a) {
         // row-reuse kernel: 3x3 filters, 128-pixel tiles made of whole image rows (and an LDS image that fits: W >= 4)
         const bool rr_ok = !g_no_reuse && a->KH == 3 && a->KW == 3 && a->W >= 4 && 128 % a->W == 0 &&
                            rr_lds_bytes(np, 128, a->W, c.bn) <= LDS_CAP;
-        split_tile_cfg(a, M, ntile, nsteps, c, rr_ok && g_no_2d);
+        split_tile_cfg(a, M, ntile, nsteps, c, rr_ok);
         if (rr_ok && c.tm == 2) c.reuse = 1;
         // 8-wave / 256-pixel form of the row-reuse kernel (one workgroup per CU = 256 slots).  Measured (B=8, 128x128:
         // exactly 2 rounds) +4-5 %; at B=9 (2.25 rounds) -5 %: the coarser tile makes the tail worse.  So: unsplit
@@ -1985,13 +1466,6 @@ static TileCfg conv_tile_cfg(const evc_conv_args* a) {
                 c.bm = 256;
                 c.tiles = t256;
             }
-        }
-        // 2-D patch tiles: half the activation staging per MFMA.  128-pixel tiles only (same tile count as the row form,
-        // so the split choice above stands); wins over the 256-pixel row tiles too (measured).
-        if (!g_no_reuse && !g_no_2d && c.tm == 2 && tile2d_ltw(a) && tile2d_lds_bytes(np, tile2d_ltw(a), c.bn) <= LDS_CAP) {
-            c.reuse = 2;
-            c.bm = 128;
-            c.tiles = (M / 128) * ntile;
         }
     } else {
         c.tail_first = 0; c.tail_tiles = 0; c.tail_splits = 1; c.tail_sps = 0;
@@ -2010,8 +1484,8 @@ static TileCfg conv_tile_cfg(const evc_conv_args* a) {
         }
         c.splits = (int)splits;
     }
-    // splits of the row-reuse kernel cover whole (chunk, kernel row) groups: 3 taps; of the 2-D form whole chunks: 9 taps
-    const int unit = c.reuse == 2 ? 9 : (c.reuse ? a->KW : 1);
+    // splits of the row-reuse kernel cover whole (chunk, kernel row) groups: 3 taps
+    const int unit = c.reuse ? a->KW : 1;
     int sps = (nsteps + c.splits - 1) / c.splits;
     sps = (sps + unit - 1) / unit * unit;
     c.steps_per_split = sps;
@@ -2022,7 +1496,6 @@ static TileCfg conv_tile_cfg(const evc_conv_args* a) {
 extern "C" int evc_conv_set_option(const char* name, int value) {
     if (!name) return EVC_EINVAL;
     const auto is = [&](const char* s) { int i = 0; while (s[i] && s[i] == name[i]) ++i; return s[i] == 0 && name[i] == 0; };
-    if (is("tiles2d")) { g_no_2d = !value; return EVC_OK; }
     if (is("wide_tiles")) { g_wide_tiles = value; return EVC_OK; }
     if (is("row_reuse")) { g_no_reuse = !value; return EVC_OK; }
     if (is("tail_split")) { g_tail_split = value; return EVC_OK; }
@@ -2122,20 +1595,6 @@ static int launch_split_rr(int mode, dim3 grid, size_t lds, hipStream_t st, cons
     return rc;
 }
 
-template <int NP, int TN>
-static int launch_split_2d(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k, int ltw) {
-    int rc = EVC_OK;
-#define EVC_CALL(M)                                                                                                   \
-    {                                                                                                                 \
-        static unsigned long long attr_done = 0;                                                                      \
-        rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_split_2d_kernel<NP, TN, M>), &attr_done, lds);    \
-        if (rc == EVC_OK) hipLaunchKernelGGL((conv_split_2d_kernel<NP, TN, M>), grid, dim3(256), lds, st, k, ltw);    \
-    }
-    EVC_MODE_SWITCH(mode, EVC_CALL)
-#undef EVC_CALL
-    return rc;
-}
-
 #define EVC_TN_SWITCH(tn, CALL) ((tn) == 3 ? CALL(3) : (tn) == 2 ? CALL(2) : CALL(1))
 
 extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stream) {
@@ -2192,15 +1651,7 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     hipStream_t st = (hipStream_t)stream;
     if (is_split_arith(a->arith)) {
         const int np = arith_planes(a->arith);
-        if (cfg.reuse == 2) {
-            const int ltw = tile2d_ltw(a);
-            const size_t lds2 = (size_t)tile2d_lds_bytes(np, ltw, cfg.bn);
-#define EVC_2D_3(TN) launch_split_2d<3, TN>(mode, grid, lds2, st, k, ltw)
-#define EVC_2D_2(TN) launch_split_2d<2, TN>(mode, grid, lds2, st, k, ltw)
-            rc = np == 3 ? EVC_TN_SWITCH(cfg.tn, EVC_2D_3) : EVC_TN_SWITCH(cfg.tn, EVC_2D_2);
-#undef EVC_2D_3
-#undef EVC_2D_2
-        } else if (cfg.reuse) {
+        if (cfg.reuse) {
             const size_t lds_rr = (size_t)rr_lds_bytes(np, cfg.bm, a->W, cfg.bn);
 #define EVC_RR4_3(TN) launch_split_rr<3, 4, TN>(mode, grid, lds_rr, st, k)
 #define EVC_RR2_3(TN) launch_split_rr<3, 2, TN>(mode, grid, lds_rr, st, k)

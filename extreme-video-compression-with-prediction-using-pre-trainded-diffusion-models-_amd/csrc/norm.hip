@@ -67,13 +67,24 @@ struct CoefArgs {
     const float* gamma; const float* beta; const float* ss; int ss_ld; const int* row;
     float* coef_a; float* coef_s;
     unsigned* bound_bits;      // optional: atomicMax of the bit pattern of the largest {sum of squares} entry seen
+    unsigned* events;          // optional: sticky range-event word (EVC_RANGE_*), OR-ed, never cleared by a kernel
 };
+
+// fp16-split arithmetic (EVC_ARITH_F16X3) scales GroupNorm-ed operands by 8: they must stay below 65504 / 8
+constexpr float F16_OPERAND_LIMIT = 65504.0f / 8.0f;
+constexpr unsigned NAN_BITS = 0x7fc00000u;      // as a bound word: "the tensor holds a non-finite element"
+
+__device__ __forceinline__ void raise_event(unsigned* events, unsigned bits) {
+    // the word only ever gains bits: skip the atomic when they are already there (the common case is "nothing to report")
+    if (events && (__hip_atomic_load(events, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bits) != bits) atomicOr(events, bits);
+}
 
 // grid (groups, B), block 256: the (split, channel) moments of one group are summed in double by the whole
 // block (fixed assignment + fixed tree => deterministic), then the group's channels get their coefficients.
 __global__ __launch_bounds__(256) void gn_coeffs_kernel(CoefArgs a) {
     __shared__ double red[2][4];
     __shared__ float redmx[4];
+    __shared__ unsigned redbad[4];
     const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int C = a.C0 + a.C1;
     const int cpg = C / a.groups;
@@ -91,20 +102,21 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(CoefArgs a) {
     }
     double sm = 0.0, sq = 0.0;
     float mx = 0.f;            // largest sum-of-squares entry: sqrt(mx) bounds every element of the tensor(s)
+    unsigned bad = 0;          // a moment that is not finite: the tensor holds a NaN / inf (fmaxf would drop a NaN silently)
     // channels of this group that live in source 0 / source 1
     const int n0 = max(0, min(c_begin + cpg, a.C0) - c_begin);
     const int n1 = cpg - n0;
     for (int i = tid; i < n0 * a.nsplit0; i += 256) {
         const int s = i / n0, cc = c_begin + (i - s * n0);
         const float2 e = *reinterpret_cast<const float2*>(a.part0 + ((size_t)(b * a.nsplit0 + s) * a.C0 + cc) * 2);
-        sm += (double)e.x; sq += (double)e.y; mx = fmaxf(mx, e.y);
+        sm += (double)e.x; sq += (double)e.y; mx = fmaxf(mx, e.y); bad |= !(fabsf(e.x) < 3.0e38f) | !(e.y < 3.0e38f);
     }
     if (n1 > 0) {
         const int c1 = c_begin + n0 - a.C0;
         for (int i = tid; i < n1 * a.nsplit1; i += 256) {
             const int s = i / n1, cc = c1 + (i - s * n1);
             const float2 e = *reinterpret_cast<const float2*>(a.part1 + ((size_t)(b * a.nsplit1 + s) * a.C1 + cc) * 2);
-            sm += (double)e.x; sq += (double)e.y; mx = fmaxf(mx, e.y);
+            sm += (double)e.x; sq += (double)e.y; mx = fmaxf(mx, e.y); bad |= !(fabsf(e.x) < 3.0e38f) | !(e.y < 3.0e38f);
         }
     }
 #pragma unroll
@@ -113,15 +125,21 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(CoefArgs a) {
         sq += __shfl_xor(sq, off);
         mx = fmaxf(mx, __shfl_xor(mx, off));
     }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = sm; red[1][tid >> 6] = sq; redmx[tid >> 6] = mx; }
+    bad = __any(bad) ? 1u : 0u;
+    if ((tid & 63) == 0) { red[0][tid >> 6] = sm; red[1][tid >> 6] = sq; redmx[tid >> 6] = mx; redbad[tid >> 6] = bad; }
     __syncthreads();
+    bad = redbad[0] | redbad[1] | redbad[2] | redbad[3];
+    const float gmx = fmaxf(fmaxf(redmx[0], redmx[1]), fmaxf(redmx[2], redmx[3]));
     // max is order-independent, so the atomic keeps the result deterministic; non-negative floats order like their bits.
     // One atomic per block, and none when the word already holds a larger value (it only ever grows): 288 blocks hitting
     // one address cost the launch 2-3 us otherwise.
+    // A non-finite moment turns the bound into the NaN pattern (it orders above every finite value and infinity): the
+    // consumer's scale becomes NaN and its output with it -- a NaN / inf in the tensor is never turned into finite numbers.
     if (a.bound_bits && tid == 0) {
-        const unsigned bits = __float_as_uint(fmaxf(fmaxf(redmx[0], redmx[1]), fmaxf(redmx[2], redmx[3])));
+        const unsigned bits = bad ? NAN_BITS : __float_as_uint(gmx);
         if (bits > __hip_atomic_load(a.bound_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.bound_bits, bits);
     }
+    if (bad && tid == 0) raise_event(a.events, EVC_RANGE_NONFINITE);
     sm = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     sq = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     const double n = (double)cpg * (double)a.HW;
@@ -130,6 +148,9 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(CoefArgs a) {
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
     const float fmean = (float)mean;
+    const float xmax = sqrtf(gmx);          // every element of this group's channels satisfies |x| <= xmax
+    bool wide = false;
+    float amax = 0.f, smax = 0.f;           // largest |mul| * rstd and |add| among this thread's channels
     for (int i = tid; i < cpg; i += 256) {
         const int c = c_begin + i;
         float mul = pmul, add = padd;
@@ -142,27 +163,82 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(CoefArgs a) {
             }
         }
         const float ca = rstd * mul;
+        const float cs = add - fmean * ca;
         a.coef_a[(size_t)b * C + c] = ca;
-        a.coef_s[(size_t)b * C + c] = add - fmean * ca;
+        a.coef_s[(size_t)b * C + c] = cs;
+        amax = fmaxf(amax, fabsf(ca)); smax = fmaxf(smax, fabsf(add));
+        // x*ca + cs = (x - mean)*ca + add and |SiLU(v)| <= |v|: while |ca| (xmax + |mean|) + |add| stays below the fp16-split
+        // kernels' operand limit no element of the normalised tensor can leave fp16's range (a sufficient condition, checked
+        // on O(B*C) numbers here instead of on every element inside the convolution's K loop)
+        wide |= !(fabsf(ca) * (xmax + fabsf(fmean)) + fabsf(add) < F16_OPERAND_LIMIT);
+    }
+    if (!a.events) return;                    // uniform
+    if (!__syncthreads_or(wide)) return;
+    if (bad) { if (tid == 0) raise_event(a.events, EVC_RANGE_NONFINITE); return; }
+    // Rare path.  The cheap test failed (e.g. a near-constant group: rstd is huge, |x - mean| tiny): bound |x - mean| per
+    // element by the deviation of its own moment entry, sum (x - mean)^2 = sumsq - 2 mean sum + n mean^2 over the entry's
+    // pixels, n <= ceil(HW / nsplit) (a larger n only loosens the bound), plus a rounding allowance.
+    float dev = 0.f;
+    {
+        const float n0f = (float)((a.HW + a.nsplit0 - 1) / a.nsplit0);
+        for (int i = tid; i < n0 * a.nsplit0; i += 256) {
+            const int s = i / n0, cc = c_begin + (i - s * n0);
+            const float2 e = *reinterpret_cast<const float2*>(a.part0 + ((size_t)(b * a.nsplit0 + s) * a.C0 + cc) * 2);
+            dev = fmaxf(dev, e.y - 2.f * fmean * e.x + n0f * fmean * fmean + 1e-5f * (e.y + n0f * fmean * fmean));
+        }
+        if (n1 > 0) {
+            const int c1 = c_begin + n0 - a.C0;
+            const float n1f = (float)((a.HW + a.nsplit1 - 1) / a.nsplit1);
+            for (int i = tid; i < n1 * a.nsplit1; i += 256) {
+                const int s = i / n1, cc = c1 + (i - s * n1);
+                const float2 e = *reinterpret_cast<const float2*>(a.part1 + ((size_t)(b * a.nsplit1 + s) * a.C1 + cc) * 2);
+                dev = fmaxf(dev, e.y - 2.f * fmean * e.x + n1f * fmean * fmean + 1e-5f * (e.y + n1f * fmean * fmean));
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        dev = fmaxf(dev, __shfl_xor(dev, off));
+        amax = fmaxf(amax, __shfl_xor(amax, off));
+        smax = fmaxf(smax, __shfl_xor(smax, off));
+    }
+    __shared__ float red3[3][4];
+    if ((tid & 63) == 0) { red3[0][tid >> 6] = dev; red3[1][tid >> 6] = amax; red3[2][tid >> 6] = smax; }
+    __syncthreads();
+    if (tid == 0) {
+        dev = fmaxf(fmaxf(red3[0][0], red3[0][1]), fmaxf(red3[0][2], red3[0][3]));
+        amax = fmaxf(fmaxf(red3[1][0], red3[1][1]), fmaxf(red3[1][2], red3[1][3]));
+        smax = fmaxf(fmaxf(red3[2][0], red3[2][1]), fmaxf(red3[2][2], red3[2][3]));
+        if (!(amax * sqrtf(fmaxf(dev, 0.f)) + smax < F16_OPERAND_LIMIT)) raise_event(a.events, EVC_RANGE_F16_OPERAND);
     }
 }
 
 // max over channel ranges of a moments tensor [B][nsplit][C][2]: the bound of a tensor that has no GroupNorm in
 // front of it (evc_moments_bound_f32).  grid (nsplit, B, ranges): range z = channels [c_begin + z*c_count, +c_count).
 __global__ __launch_bounds__(256) void moments_bound_kernel(const float* __restrict__ part, int nsplit, int C, int c_begin,
-                                                            int c_count, unsigned* __restrict__ bound_bits) {
+                                                            int c_count, unsigned* __restrict__ bound_bits,
+                                                            unsigned* __restrict__ events) {
     const float* row = part + ((size_t)(blockIdx.y * nsplit + blockIdx.x) * C + c_begin + blockIdx.z * c_count) * 2;
     bound_bits += blockIdx.z;
     float mx = 0.f;
-    for (int i = threadIdx.x; i < c_count; i += 256) mx = fmaxf(mx, row[2 * i + 1]);
+    unsigned bad = 0;
+    for (int i = threadIdx.x; i < c_count; i += 256) {
+        const float2 e = *reinterpret_cast<const float2*>(row + 2 * i);
+        mx = fmaxf(mx, e.y);
+        bad |= !(fabsf(e.x) < 3.0e38f) | !(e.y < 3.0e38f);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    bad = __any(bad) ? 1u : 0u;
     __shared__ float redmx[4];
-    if ((threadIdx.x & 63) == 0) redmx[threadIdx.x >> 6] = mx;
+    __shared__ unsigned redbad[4];
+    if ((threadIdx.x & 63) == 0) { redmx[threadIdx.x >> 6] = mx; redbad[threadIdx.x >> 6] = bad; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned bits = __float_as_uint(fmaxf(fmaxf(redmx[0], redmx[1]), fmaxf(redmx[2], redmx[3])));
+        bad = redbad[0] | redbad[1] | redbad[2] | redbad[3];
+        const unsigned bits = bad ? NAN_BITS : __float_as_uint(fmaxf(fmaxf(redmx[0], redmx[1]), fmaxf(redmx[2], redmx[3])));
         if (bits > __hip_atomic_load(bound_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(bound_bits, bits);
+        if (bad) raise_event(events, EVC_RANGE_NONFINITE);
     }
 }
 
@@ -256,36 +332,36 @@ extern "C" int evc_chan_stats_f32(const float* x, float* partial, int B, int HW,
 extern "C" int evc_gn_coeffs_bound_f32(const float* part0, int nsplit0, int C0, const float* part1, int nsplit1, int C1,
                                        int B, int HW, int groups, float eps, int mode, const float* gamma,
                                        const float* beta, const float* ss, int ss_ld, const int* row, float* coef_a,
-                                       float* coef_s, unsigned* bound_bits, void* stream);
+                                       float* coef_s, unsigned* bound_bits, unsigned* events, void* stream);
 
 extern "C" int evc_gn_coeffs_f32(const float* part0, int nsplit0, int C0, const float* part1, int nsplit1, int C1,
                                  int B, int HW, int groups, float eps, int mode, const float* gamma,
                                  const float* beta, const float* ss, int ss_ld, const int* row, float* coef_a,
                                  float* coef_s, void* stream) {
     return evc_gn_coeffs_bound_f32(part0, nsplit0, C0, part1, nsplit1, C1, B, HW, groups, eps, mode, gamma, beta, ss,
-                                   ss_ld, row, coef_a, coef_s, nullptr, stream);
+                                   ss_ld, row, coef_a, coef_s, nullptr, nullptr, stream);
 }
 
 extern "C" int evc_moments_bound_f32(const float* part, int nsplit, int C, int c_begin, int c_count, int n_ranges, int B,
-                                     unsigned* bound_bits, void* stream) {
+                                     unsigned* bound_bits, unsigned* events, void* stream) {
     if (!part || !bound_bits || nsplit <= 0 || C <= 0 || B <= 0 || c_begin < 0 || c_count <= 0 || n_ranges <= 0 ||
         c_begin + (long long)n_ranges * c_count > C)
         return EVC_EINVAL;
     hipLaunchKernelGGL(moments_bound_kernel, dim3(nsplit, B, n_ranges), dim3(256), 0, (hipStream_t)stream, part, nsplit, C,
-                       c_begin, c_count, bound_bits);
+                       c_begin, c_count, bound_bits, events);
     return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
 }
 
 extern "C" int evc_gn_coeffs_bound_f32(const float* part0, int nsplit0, int C0, const float* part1, int nsplit1, int C1,
                                        int B, int HW, int groups, float eps, int mode, const float* gamma,
                                        const float* beta, const float* ss, int ss_ld, const int* row, float* coef_a,
-                                       float* coef_s, unsigned* bound_bits, void* stream) {
+                                       float* coef_s, unsigned* bound_bits, unsigned* events, void* stream) {
     if (!part0 || C0 <= 0 || nsplit0 <= 0 || C1 < 0 || (C1 > 0 && (!part1 || nsplit1 <= 0))) return EVC_EINVAL;
     if (B <= 0 || HW <= 0 || groups <= 0 || (C0 + C1) % groups != 0 || !coef_a || !coef_s) return EVC_EINVAL;
     if (mode < 0 || mode > 2 || (mode == 1 && (!gamma || !beta)) || (mode == 2 && (!ss || ss_ld < 2 * (C0 + C1))))
         return EVC_EINVAL;
     CoefArgs a{part0, nsplit0, C0, part1, nsplit1, C1, B, HW, groups, eps, mode, gamma, beta, ss, ss_ld, row,
-               coef_a, coef_s, bound_bits};
+               coef_a, coef_s, bound_bits, events};
     hipLaunchKernelGGL(gn_coeffs_kernel, dim3(groups, B), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
 }

@@ -130,6 +130,16 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def gather_over_ranks(value, device):
+    """Every rank's value, in rank order, on every rank (one small all_gather)."""
+    if not dist.is_initialized():
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def sum_over_ranks(value, device):
     if not dist.is_initialized():
         return float(value)

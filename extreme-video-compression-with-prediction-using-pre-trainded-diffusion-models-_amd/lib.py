@@ -86,8 +86,8 @@ HIP_SYMBOLS = {
                                   c_void_p]),
     "evc_gn_coeffs_bound_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                         c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                        c_void_p, c_void_p]),
-    "evc_moments_bound_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+                                        c_void_p, c_void_p, c_void_p]),
+    "evc_moments_bound_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "evc_attention_f16x3_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_float, c_void_p, c_void_p, c_void_p]),
     "evc_deconv5x5s2_phase_weights_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -289,6 +289,33 @@ def chan_stats(x):
     return part
 
 
+# Sticky range-event word of the fp16-split arithmetic (include/evc_hip.h EVC_RANGE_*), one per device: the coefficient /
+# bound kernels OR bits into it when a tensor holds a NaN / inf or when a GroupNorm-ed operand may leave fp16's range.
+RANGE_NONFINITE, RANGE_F16_OPERAND = 1, 2
+_range_words = {}
+
+
+def _events(device):
+    w = _range_words.get(device.index)
+    if w is None:
+        w = _range_words[device.index] = torch.zeros(1, dtype=torch.int32, device=device)
+    return w
+
+
+def range_events(device=None, reset=False):
+    """Bits raised so far on ``device`` (default: current): 0 = every fp16-split operand was provably in range and
+    every tensor finite.  Synchronises the device.  RANGE_F16_OPERAND set means a trained checkpoint drives a normalised
+    activation towards fp16's limit: run that model with EVC_CONV_ARITH=bf16x6 (exact 3-way bf16 split, no range limit)."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    w = _range_words.get(idx)
+    if w is None:
+        return 0
+    v = int(w.item())
+    if reset:
+        w.zero_()
+    return v
+
+
 def gn_coeffs(parts, HW, groups, eps, mode=0, gamma=None, beta=None, ss=None, row=None, bound=None):
     """parts: one or two partial-moment tensors (virtual concat). Returns (coef_a, coef_s), each (B, C).
     ``bound``: optional one-element int32 tensor (zeroed by the caller) raised to the bit pattern of the tensors'
@@ -304,7 +331,8 @@ def gn_coeffs(parts, HW, groups, eps, mode=0, gamma=None, beta=None, ss=None, ro
     ss_ld = 0 if ss is None else ss.stride(0)
     _check(L.evc_gn_coeffs_bound_f32(fptr(p0), ns0, C0, fptr(p1), ns1, C1, B, HW, groups, eps, mode, fptr(gamma),
                                      fptr(beta), c_void_p(ss.data_ptr()) if ss is not None else None, ss_ld,
-                                     fptr(row, torch.int32), fptr(ca), fptr(cs), _word(bound), stream_ptr()),
+                                     fptr(row, torch.int32), fptr(ca), fptr(cs), _word(bound), _word(_events(p0.device)),
+                                     stream_ptr()),
            "evc_gn_coeffs_bound_f32")
     return ca, cs
 
@@ -322,7 +350,8 @@ def moments_bound(part, c_begin, c_count, bound):
     (B, ns, C, 2), for z < bound.numel()."""
     B, ns, C, _ = part.shape
     n = bound.numel()
-    _check(hip_lib().evc_moments_bound_f32(fptr(part), ns, C, c_begin, c_count, n, B, _word(bound, n), stream_ptr()),
+    _check(hip_lib().evc_moments_bound_f32(fptr(part), ns, C, c_begin, c_count, n, B, _word(bound, n),
+                                           _word(_events(part.device)), stream_ptr()),
            "evc_moments_bound_f32")
 
 
@@ -389,7 +418,7 @@ def conv_pack_weights(w, arith=None):
 
 
 def conv_set_option(name, value):
-    """Dispatch switches of the convolution ("tiles2d", "wide_tiles", "row_reuse", "tail_split"): include/evc_hip.h."""
+    """Dispatch switches of the convolution ("wide_tiles", "row_reuse", "tail_split"): include/evc_hip.h."""
     _check(hip_lib(require_device=False).evc_conv_set_option(name.encode(), int(value)), "evc_conv_set_option")
 
 

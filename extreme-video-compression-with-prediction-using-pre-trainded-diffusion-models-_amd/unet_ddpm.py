@@ -13,7 +13,11 @@ builds this network -- it is the file BASELINE.json names; section 8f item 4).  
 * stride-2 convolutions = "same" convolution + decimation (``evc_upfirdn2d_nhwc_f32``, 1x1 kernel, down 2);
   ``nn.Upsample(nearest)`` = ``evc_upfirdn2d_nhwc_f32`` with a 2x2 box kernel, up 2, pad (1, 0);
 * attention = one head of width C (``AttnBlock``, models/unet.py:102-123): Q | K | V ``Nin`` as one 1x1 conv,
-  ``evc_attention_f32`` / ``evc_attention_f16x3_f32`` (C in {32, 64, 128, 192}), ``OUT`` with the residual.
+  ``evc_attention_f32`` / ``evc_attention_f16x3_f32``, ``OUT`` with the residual.  The attention kernels exist for head
+  widths 32, 64 and 192 only (csrc/attention.hip); this network attends at width 2*ngf (and at the deepest level's width
+  in the middle block), so it runs for ``model.ngf`` in {16, 32, 96} with ``mode: deep`` -- any other width,
+  including the mine.yml value ngf = 192 (attention at 384 channels in ONE head), raises ``NotImplementedError`` from the
+  constructor, before any kernel is launched.
 """
 import math
 
@@ -22,6 +26,8 @@ import torch
 
 from . import lib as L
 from .scorenet import _Act, _pad16
+
+ATTENTION_WIDTHS = (32, 64, 192)      # head widths attention_dispatch (csrc/attention.hip) instantiates
 
 BOX2 = np.ones((2, 2), dtype=np.float32)
 ONE = np.ones((1, 1), dtype=np.float32)
@@ -65,6 +71,16 @@ class UNetDDPM:
     """HIP implementation of ``UNet_DDPM`` (eval mode, dropout 0, noise_in_cond / gamma / output_all_frames off)."""
 
     def __init__(self, config, state_dict, device="cuda", prefix=""):
+        m_ = config.model
+        mode_ = getattr(config, "mode", "deep")
+        widths = sorted({m["ch"] for _, _, m in build_program(m_.ngf, mode_, 1) if m["kind"] == "attn"})
+        bad = [w for w in widths if w not in ATTENTION_WIDTHS]
+        if bad:
+            raise NotImplementedError(
+                f"UNetDDPM with ngf={m_.ngf} (mode {mode_!r}) attends in one head of width "
+                f"{bad}; the HIP attention kernels exist for widths {list(ATTENTION_WIDTHS)} only, i.e. ngf in (16, 32, 96) "
+                f"with mode 'deep'.  (The network the reference CLI builds, arch 'unetmore', has 192-wide heads and is "
+                f"fully supported.)")
         L.hip_lib()
         m, d = config.model, config.data
         if getattr(m, "noise_in_cond", False) or getattr(m, "gamma", False) or getattr(m, "output_all_frames", False):

@@ -87,18 +87,31 @@ int evc_gn_coeffs_f32(const float* part0, int nsplit0, int C0, const float* part
                       int HW, int groups, float eps, int mode, const float* gamma, const float* beta,
                       const float* ss, int ss_ld, const int* row, float* coef_a, float* coef_s, void* stream);
 
+/* Range events of the fp16-split arithmetic (EVC_ARITH_F16X3).  That arithmetic scales its operands by powers of two
+ * into fp16's range WITHOUT clamping: an operand element beyond the range becomes inf in the split and NaN in the output
+ * (loud, never a silently saturated number), and a NaN / inf input stays non-finite.  Whether that can happen is decided
+ * on O(B*C) numbers by the kernels that see every tensor's moments -- the two functions below -- which OR these bits into
+ * the caller's sticky device word `events` (may be NULL; never cleared by a kernel):
+ *   EVC_RANGE_NONFINITE    a tensor's moments are not finite: it holds a NaN or an infinity;
+ *   EVC_RANGE_F16_OPERAND  for some channel |coef_a| * max|x| + |coef_s| >= 65504 / 8: a GroupNorm-ed (and activated,
+ *                          |SiLU(v)| <= |v|) operand element MAY leave fp16's range.  Zero means none can (a sufficient
+ *                          condition).  Remedy: EVC_ARITH_BF16X6 for that model (host: EVC_CONV_ARITH=bf16x6). */
+#define EVC_RANGE_NONFINITE 1u
+#define EVC_RANGE_F16_OPERAND 2u
+
 /* evc_gn_coeffs_f32 that additionally raises *bound_bits (atomic max; the caller zeroes it first) to the bit pattern of
  * the largest {sum of squares} entry among the moments it read: sqrt of that float bounds every element of the tensor(s),
- * because each element belongs to exactly one entry.  Deterministic (max is order-independent).  bound_bits may be NULL. */
+ * because each element belongs to exactly one entry (the NaN pattern 0x7fc00000 when a moment is not finite: consumers
+ * then scale by NaN).  Deterministic (max is order-independent).  bound_bits and events may be NULL. */
 int evc_gn_coeffs_bound_f32(const float* part0, int nsplit0, int C0, const float* part1, int nsplit1, int C1, int B,
                             int HW, int groups, float eps, int mode, const float* gamma, const float* beta,
                             const float* ss, int ss_ld, const int* row, float* coef_a, float* coef_s,
-                            unsigned* bound_bits, void* stream);
+                            unsigned* bound_bits, unsigned* events, void* stream);
 /* The same bound over n_ranges consecutive channel ranges [c_begin + z*c_count, + c_count) of one moments tensor
  * [B][nsplit][C][2], range z into bound_bits[z] (for tensors that are not followed by a GroupNorm: the q | k | v
  * projection feeding attention has three). */
 int evc_moments_bound_f32(const float* part, int nsplit, int C, int c_begin, int c_count, int n_ranges, int B,
-                          unsigned* bound_bits, void* stream);
+                          unsigned* bound_bits, unsigned* events, void* stream);
 
 /* y = act(x*coef_a[b][c] + coef_s[b][c]) elementwise on NHWC: the stand-alone form of the fused load.  One pass per
  * tensor instead of once per filter tap inside the convolution (SiLU costs MFMA issue slots there; HBM is cheap).
@@ -165,8 +178,9 @@ int evc_conv_pack_weights_f32(const float* w, float* packed, int Co, int Ci, int
 long long evc_conv_packed_bytes(int Co, int Ci, int KH, int KW, int arith);
 int evc_conv_pack_weights(const float* w, void* packed, int Co, int Ci, int KH, int KW, int arith, void* stream);
 /* Process-wide tuning switches of the convolution dispatch (A/B measurements, tests of non-default kernels; results are
- * the same up to fp32 summation order): "tiles2d" (default 0: 2-D patch tiles for 3x3 filters), "wide_tiles" (default 1:
- * 256-pixel row tiles on large unsplit grids), "row_reuse" (default 1).  Returns EVC_EINVAL for an unknown name. */
+ * the same up to fp32 summation order): "wide_tiles" (default 1: 256-pixel row tiles on large unsplit grids), "row_reuse"
+ * (default 1: the row-reuse kernel for 3x3 filters), "tail_split" (default 1: K-split tail of 1.x / 2.x-round grids).
+ * Returns EVC_EINVAL for an unknown name. */
 int evc_conv_set_option(const char* name, int value);
 int evc_conv_choose_splits(const evc_conv_args* a);
 /* The number of pixel runs per image (H*W/64 or H*W/32) for which the fused moments will be written, when they are

@@ -223,6 +223,20 @@ def gen_traj_full():
          stats=torch.stack([o.mean(), o.std(), o.abs().max()]))
 
 
+def gen_traj_fpndm_full():
+    """BASELINE configs[4]'s sampler at full size: F-PNDM with 10 subsampled steps (3 Runge-Kutta warm-up iterations of 4
+    forwards + 7 Adams-Bashforth ones = 19 full-size reference forwards, fractional and negative labels), B=2.
+    Reference: models/__init__.py:39-100, models/pndm.py:3-52."""
+    from models import FPNDM_sampler
+    torch.set_num_threads(8)
+    net, d = ref_net(192, 192, 128, 1234)
+    x_T, cond = rnd(821, 2, 15, 128, 128), rnd(822, 2, 6, 128, 128)
+    out = FPNDM_sampler(x_T.clone(), net, cond=cond, subsample_steps=10, final_only=True, clip_before=True)
+    o = out[0] if out.dim() == 5 else out
+    save("traj_fpndm_full", samples=o.reshape(2, -1)[:, ::30].clone(), first_row=o[:, :, 0, :].clone(),
+         stats=torch.stack([o.mean(), o.std(), o.abs().max()]))
+
+
 def gen_unet_ddpm():
     """The reference's alternative score network models/unet.py::UNet_DDPM (reduced: ngf 32, 32x32), with and without
     time conditioning, through its own forward and through the reference DDPM sampler."""
@@ -294,10 +308,10 @@ if __name__ == "__main__":
     a = ap.parse_args()
     gens = dict(schedule=gen_schedule, fir=gen_fir, blocks=gen_blocks, forward_reduced=gen_forward_reduced,
                 samplers=gen_samplers, forward_full=gen_forward_full, forward_full_b9=gen_forward_full_b9,
-                traj_full=gen_traj_full, unet_ddpm=gen_unet_ddpm, forward_spade=gen_forward_spade)
+                traj_full=gen_traj_full, traj_fpndm_full=gen_traj_fpndm_full, unet_ddpm=gen_unet_ddpm, forward_spade=gen_forward_spade)
     for name, fn in gens.items():
         if a.only and name != a.only:
             continue
-        if a.skip_full and name in ("forward_full", "forward_full_b9", "traj_full"):
+        if a.skip_full and name in ("forward_full", "forward_full_b9", "traj_full", "traj_fpndm_full"):
             continue
         fn()

@@ -178,3 +178,53 @@ def test_clip_decoder_with_the_spade_network_vs_oracle():
     assert float((out[:, 2:7] - g1).abs().max()) < 2e-3
     g2 = oracle_chunk(out[:, 5:7], noise_log[inits[1]:])
     assert float((out[:, 7:12] - g2).abs().max()) < 2e-3
+
+
+def test_full_size_clip_decoder_two_chunks_at_a_rank_batch_vs_oracle():
+    """BASELINE configs[2]'s per-rank shape through the receiver loop at FULL size: six 128x128 clips (one rank of the
+    46-clip shard), two ELIC key frames + two generated chunks (the second conditioned on frames the first produced),
+    262 M-parameter network at B = 6 per launch, 2 DDPM steps + the denoise call per chunk; the first chunk is
+    regenerated by the CPU oracle sampler + oracle network from the decoded key frames and the same injected noise."""
+    import evc_amd  # noqa: F401
+    from evc_amd import sampler as S, synthetic
+    from evc_amd.config import default_config
+    from evc_amd.decoder import ClipDecoder
+    from evc_amd.elic import ElicModel
+    from evc_amd.scorenet import ScoreNet
+    from oracle import samplers as OS, schedule as OSch, scorenet as ON
+    torch.set_num_threads(16)
+    cfg = default_config(192, 192, 128, subsample=2)
+    d_net = ON.Dims()
+    p = ON.seeded_params(d_net, 1234)
+    net = ScoreNet(cfg, p)
+    elic = ElicModel(synthetic.elic_state_dict(3))
+    dec = ClipDecoder(net, elic, cfg, S.get_sampler("DDPM"))
+    B, F = 6, 12
+    clips = torch.from_numpy(synthetic.make_clips(B, seed=8, frames=2).astype(np.float32) / 255)
+    key_strings, shape = [], None
+    for f in (0, 1):
+        enc = elic.compress(clips[:, f].cuda())
+        key_strings.append(enc["strings"])
+        shape = enc["shape"]
+    mask = np.array([1, 1] + [0] * 10)
+    noise_log = []
+
+    def noise_fn(tag, shp):
+        tns = rnd(3000 + len(noise_log), *shp)
+        noise_log.append((tag, tns))
+        return tns.cuda()
+    out = dec.decode(mask, key_strings, shape, frames=F, noise_fn=noise_fn).cpu()
+    assert out.shape == (B, F, 3, 128, 128) and bool(torch.isfinite(out).all())
+    from evc_amd import lib as L
+    assert L.range_events() == 0          # no fp16-split operand could leave its range, no tensor held a NaN / inf
+    inits = [i for i, (tag, _) in enumerate(noise_log) if tag == "init"]
+    assert len(inits) == 2
+    log = noise_log[inits[0]:inits[1]]
+    cond = 2 * out[:, 0:2].reshape(B, 6, 128, 128) - 1
+    steps = {tag: tns for tag, tns in log[1:]}
+    x = OS.ddpm(log[0][1].clone(), lambda xx, tt: ON.forward(p, d_net, xx, tt, cond=cond), OSch.base_schedule(),
+                subsample_steps=2, noise_fn=lambda i, xx: steps[i])
+    g1 = ((x[0] + 1) / 2).clamp(0, 1).reshape(B, 5, 3, 128, 128)
+    assert float((out[:, 2:7] - g1).abs().max()) < 2e-3              # fp32 sampler tolerance on [0,1] pixels
+    # the second chunk was conditioned on generated frames 5, 6 (not on the key frames): it differs from the first
+    assert float((out[:, 7:12] - out[:, 2:7]).abs().max()) > 1e-3

@@ -182,33 +182,41 @@ def test_conv3x3_k_split_tail(L, split_arith, B, H, W, C0, C1, Co):
     assert rel(nchw(out), ref) < 1e-5
 
 
-@pytest.mark.parametrize("B,H,W,C0,C1,Co,splits", [(2, 32, 32, 32, 16, 192, 0), (1, 64, 64, 16, 0, 128, 2), (1, 128, 128, 16, 16, 64, 0),
-                                                    (3, 16, 16, 48, 0, 192, 3), (2, 8, 32, 16, 0, 192, 0)])
-def test_conv3x3_2d_patch_tiles(L, split_arith, B, H, W, C0, C1, Co, splits):
-    """The 2-D patch form of the 3x3 convolution (conv_split_2d_kernel, option "tiles2d": off by default because it
-    measured slower): 32x4 and 16x8 patches, image borders on all four sides, concat sources, GroupNorm+SiLU on load,
-    residual, fused moments, split-K -- same checks as the row-tile kernel."""
+@pytest.mark.parametrize("B,H,W,C0,C1,Co,K,splits", [
+    (2, 32, 32, 32, 16, 192, 3, 2),     # row-reuse kernel, blockIdx.z splits
+    (3, 8, 8, 64, 0, 192, 3, 4),        # M = 192: a partial last pixel tile
+    (2, 16, 16, 96, 32, 384, 1, 3),     # 1x1 filter: the simple-schedule kernel, two channel tiles
+    (9, 64, 64, 32, 0, 192, 3, 0),      # automatic choice on a mid-size grid
+    (5, 128, 128, 16, 16, 192, 3, 0),   # 640 tiles: one round + a K-split TAIL
+])
+def test_conv_split_k_is_deterministic_and_matches_unsplit(L, arith, B, H, W, C0, C1, Co, K, splits):
+    """Split-K launches (blockIdx.z splits and the K-split tail, partial sums to slabs + the combine kernel that adds them
+    in split order): against torch, against the same convolution forced unsplit (same values up to summation order), fused
+    moments, and bitwise run-to-run determinism."""
     x0 = rnd(50, B, C0, H, W).cuda()
     x1 = rnd(51, B, C1, H, W).cuda() if C1 else None
     C = C0 + C1
     a, s = (1 + 0.2 * rnd(52, B, C)).cuda(), (0.3 * rnd(53, B, C)).cuda()
-    w = (rnd(54, Co, C, 3, 3) / np.sqrt(9 * C)).cuda()
+    w = (rnd(54, Co, C, K, K) / np.sqrt(K * K * C)).cuda()
     b, res = rnd(55, Co).cuda(), rnd(56, B, Co, H, W).cuda()
-    xin = torch.cat([x0, x1], 1).cpu() if C1 else x0.cpu()
-    ref = (F.conv2d(silu_affine(xin, a.cpu(), s.cpu()), w.cpu(), b.cpu(), padding=1) + res.cpu()) * 0.5
-    wp = L.conv_pack_weights(w, split_arith)
-    L.conv_set_option("tiles2d", 1)
-    try:
-        out, st = L.conv2d_nhwc(nhwc(x0), wp, Co, 3, 3, bias=b, src1=None if x1 is None else nhwc(x1), coef=(a, s),
-                                act_in=L.ACT_SILU, res=nhwc(res), out_scale=0.5, splits=splits, want_stats=True)
-    finally:
-        L.conv_set_option("tiles2d", 0)
-    assert rel(nchw(out), ref) < 1e-5
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    ref = (F.conv2d(silu_affine(xin, a, s), w, b, padding=K // 2) + res) * 0.5
+    wp = L.conv_pack_weights(w, arith)
+    kw = dict(bias=b, src1=None if x1 is None else nhwc(x1), coef=(a, s), act_in=L.ACT_SILU, res=nhwc(res), out_scale=0.5,
+              want_stats=True)
+    out, st = L.conv2d_nhwc(nhwc(x0), wp, Co, K, K, splits=splits, **kw)
+    assert rel(nchw(out), ref) < 2e-5
     o = out.double().reshape(B, H * W, Co)
     assert rel(st.double().sum(1).float(), torch.stack([o.sum(1), (o * o).sum(1)], -1).float()) < 1e-5
-    rows = L.conv2d_nhwc(nhwc(x0), wp, Co, 3, 3, bias=b, src1=None if x1 is None else nhwc(x1), coef=(a, s),
-                         act_in=L.ACT_SILU, res=nhwc(res), out_scale=0.5, splits=splits)
-    assert rel(out, rows) < 2e-6                              # row tiles: same values up to summation order
+    for _ in range(3):
+        again, st2 = L.conv2d_nhwc(nhwc(x0), wp, Co, K, K, splits=splits, **kw)
+        assert torch.equal(again, out) and torch.equal(st2, st)
+    L.conv_set_option("tail_split", 0)
+    try:
+        one, _ = L.conv2d_nhwc(nhwc(x0), wp, Co, K, K, splits=1, **kw)
+    finally:
+        L.conv_set_option("tail_split", 1)
+    assert rel(out, one) < 2e-6
     with pytest.raises(L.EvcKernelError):
         L.conv_set_option("no_such_option", 1)
 
@@ -235,10 +243,11 @@ def test_conv_bf16x6_is_not_less_accurate_than_f32_mfma(L):
         assert rms3 <= 1.25 * rms32 and mx3 <= 2.0 * mx32, err
 
 
-def test_conv_f16x3_scaling_and_saturation(L):
+def test_conv_f16x3_scaling_and_loud_overflow(L):
     """EVC_ARITH_F16X3 range handling: the per-tensor weight scale makes tiny and huge weights equally accurate (the
     inverse is applied to the accumulator), small activations keep their precision (absolute error of the split is
-    2^-25 / 8), and an activation beyond fp16's range saturates at 65504 / 8 instead of producing inf - inf = NaN."""
+    2^-25 / 8).  Nothing is clamped: an activation beyond fp16's range (|x| > 65504 / 8), a NaN and an infinity all come
+    out NON-FINITE at the pixels they reach -- never as silently saturated finite numbers -- and leave the rest alone."""
     B, H, W, Ci, Co = 1, 16, 16, 64, 192
     x = rnd(70, B, Ci, H, W).cuda()
     w0 = rnd(71, Co, Ci, 3, 3) / np.sqrt(9 * Ci)
@@ -247,13 +256,66 @@ def test_conv_f16x3_scaling_and_saturation(L):
         ref = F.conv2d((x * xscale).double(), w.double(), None, padding=1)
         out = L.conv2d_nhwc(nhwc(x * xscale), L.conv_pack_weights(w, L.ARITH_F16X3), Co, 3, 3)
         assert float((nchw(out).double() - ref).abs().max() / ref.abs().max()) < 2e-6, (wscale, xscale)
-    xb = x.clone()
-    xb[0, 3, 5, 5] = 1e6                                    # far beyond 65504 / 8
-    out = L.conv2d_nhwc(nhwc(xb), L.conv_pack_weights(w0.cuda(), L.ARITH_F16X3), Co, 3, 3)
-    assert bool(torch.isfinite(out).all())
-    far = torch.ones(H, W, dtype=torch.bool); far[4:7, 4:7] = False     # pixels the outlier does not reach
+    wp = L.conv_pack_weights(w0.cuda(), L.ARITH_F16X3)
+    far = torch.ones(H, W, dtype=torch.bool); far[4:7, 4:7] = False     # pixels the bad element does not reach
     ref = F.conv2d(x.cpu(), w0, None, padding=1)
-    assert rel(nchw(out)[0][:, far], ref[0][:, far]) < 1e-5
+    for bad in (1e6, float("nan"), float("inf"), -float("inf")):         # 1e6: far beyond 65504 / 8
+        xb = x.clone()
+        xb[0, 3, 5, 5] = bad
+        out = nchw(L.conv2d_nhwc(nhwc(xb), wp, Co, 3, 3))[0].cpu()
+        assert not bool(torch.isfinite(out[:, 4:7, 4:7]).any()), bad     # every output the element feeds is non-finite
+        assert bool(torch.isfinite(out[:, far]).all()) and rel(out[:, far], ref[0][:, far]) < 1e-5, bad
+    # the largest magnitude that still fits is exact business as usual
+    xb = x.clone()
+    xb[0, 3, 5, 5] = 8000.0
+    out = nchw(L.conv2d_nhwc(nhwc(xb), wp, Co, 3, 3))
+    refb = F.conv2d(xb.double(), w0.cuda().double(), None, padding=1)
+    assert float((out.double() - refb).abs().max() / refb.abs().max()) < 2e-6
+
+
+def test_range_events_from_the_coefficient_kernels(L):
+    """include/evc_hip.h EVC_RANGE_*: the kernels that see every tensor's moments report (sticky device word) a tensor
+    that holds a NaN / inf and a GroupNorm-ed operand that may leave fp16's range; in-range finite tensors report nothing;
+    a non-finite tensor turns its element bound into NaN, so the convolution reading it through ``in_bound`` gives NaN."""
+    L.range_events(reset=True)
+    B, H, W, C = 2, 16, 16, 64
+    x = nhwc(rnd(75, B, C, H, W).cuda())
+    st = L.chan_stats(x)
+    bound = torch.zeros(1, dtype=torch.int32, device="cuda")
+    table = torch.zeros(1, 2 * C, device="cuda")
+    row = torch.zeros(B, dtype=torch.int32, device="cuda")
+    L.gn_coeffs([st], H * W, 32, 1e-5, mode=2, ss=table, row=row, bound=bound)
+    assert L.range_events() == 0
+    # AdaGN scale row of 3000: |gn(x) * 3001| can pass 8188 -> reported (a sufficient condition: "may")
+    table[0, :C] = 3000.0
+    L.gn_coeffs([st], H * W, 32, 1e-5, mode=2, ss=table, row=row)
+    assert L.range_events(reset=True) == L.RANGE_F16_OPERAND
+    assert L.range_events() == 0
+    # a NaN in the tensor: moments not finite -> NONFINITE, bound word = NaN pattern, the 1x1 convolution outputs NaN
+    xn = x.clone()
+    xn[1, 3, 3, 7] = float("nan")
+    bound.zero_()
+    ca, cs = L.gn_coeffs([L.chan_stats(xn)], H * W, 32, 1e-5, bound=bound)
+    assert L.range_events() & L.RANGE_NONFINITE
+    assert not bool(torch.isfinite(bound.view(torch.float32)).all())
+    assert not bool(torch.isfinite(ca[1]).all()) and bool(torch.isfinite(ca[0]).all())     # only the sample that holds it
+    w = (rnd(76, 192, C, 1, 1) / 8).cuda()
+    out = L.conv2d_nhwc(xn, L.conv_pack_weights(w, L.ARITH_F16X3), 192, 1, 1, in_bound=bound)
+    assert not bool(torch.isfinite(out).any())
+    # ... and through the GroupNorm-on-load path (NaN coefficients): the whole sample is NaN, the other one is untouched
+    w3 = (rnd(77, 192, C, 3, 3) / 24).cuda()
+    out = L.conv2d_nhwc(xn, L.conv_pack_weights(w3, L.ARITH_F16X3), 192, 3, 3, coef=(ca, cs), act_in=L.ACT_SILU)
+    assert not bool(torch.isfinite(out[1]).any()) and bool(torch.isfinite(out[0]).all())
+    L.range_events(reset=True)
+    qkv = L.chan_stats(nhwc(rnd(78, B, 96, H, W).cuda()))
+    b3 = torch.zeros(3, dtype=torch.int32, device="cuda")
+    L.moments_bound(qkv, 0, 32, b3)
+    assert L.range_events() == 0 and bool((b3.view(torch.float32) > 0).all())
+    qkv[0, 0, 40, 1] = float("inf")
+    b3.zero_()
+    L.moments_bound(qkv, 0, 32, b3)
+    f = b3.view(torch.float32)
+    assert L.range_events(reset=True) == L.RANGE_NONFINITE and bool(torch.isnan(f[1])) and bool(torch.isfinite(f[[0, 2]]).all())
 
 
 @pytest.mark.parametrize("K,H", [(1, 32), (3, 16)])

@@ -55,6 +55,17 @@ def full_net():
     return net
 
 
+@pytest.fixture(autouse=True)
+def no_range_events():
+    """Every network / trajectory test of this module must leave the fp16-split range-event word at zero: no tensor held
+    a NaN / inf and every GroupNorm-ed operand was provably inside fp16's range (include/evc_hip.h EVC_RANGE_*)."""
+    import evc_amd  # noqa: F401
+    from evc_amd import lib as L
+    L.range_events(reset=True)
+    yield
+    assert L.range_events() == 0
+
+
 def test_forward_full_size_against_reference_golden(full_net):
     g = golden("forward_full")
     net = full_net
@@ -103,15 +114,36 @@ def test_forward_full_size_b32_cycled_against_reference_golden(full_net):
         assert rel(o[j, ::60].numpy(), g["samples"][j % 9]) < 2e-4, j
 
 
+@pytest.mark.parametrize("B", [5, 6, 8])
+def test_forward_full_size_per_rank_batches_against_reference_golden(full_net, B):
+    """BASELINE configs[2] shards 46 clips as 6,6,6,6,6,6,5,5: a rank launches the network at B = 6 or 5 (and the CLI's
+    default --batch is 8).  Tile height, split-K factor and K-split tail are chosen per batch size, so each of these
+    launch plans is checked on its own: the first B samples of the B=9 golden batch in ONE launch of size B (the
+    reference is batch-independent, models/better/ncsnpp_more.py:251-392, so the B=9 goldens pin every slice)."""
+    g = golden("forward_full_b9")
+    x, cond = _b9_inputs()
+    o = full_net(x[:B].contiguous(), torch.tensor([500] * B), cond=cond[:B].contiguous()).cpu().reshape(B, -1)
+    for i in range(B):
+        assert rel(o[i, ::60].numpy(), g["samples"][i]) < 2e-4, (B, i)
+    st = g["stats"][:B]
+    assert np.allclose(o.mean(1).numpy(), st[:, 0], atol=2e-4 * float(st[:, 2].max()))
+    assert np.allclose(o.std(1).numpy(), st[:, 1], rtol=2e-4)
+    # the fractional F-PNDM label and DDPM's denoise label through the same launch plan
+    for key, lab in (("samples_tm05", -0.5), ("samples_t99", 99)):
+        o = full_net(x[:B].contiguous(), torch.tensor([lab] * B), cond=cond[:B].contiguous()).cpu().reshape(B, -1)
+        for i in range(2):
+            assert rel(o[i, ::60].numpy(), g[key][i]) < 2e-4, (B, key, i)
+
+
 def test_every_conv_launch_of_the_full_size_forward_against_torch(full_net):
     """Walk every DISTINCT convolution launch the full-size forward makes at the benchmark's batch sizes (B = 9:
-    configs[1]; B = 32: configs[4]) -- shape, source split, on-load transform, residual, arithmetic -- and run each
-    through the C ABI exactly as the network does (same tile / split-K / kernel choice, which depend on B) against
-    torch's fp32 convolution on the same device."""
+    configs[1]; B = 32: configs[4]; B = 5, 6: a rank of configs[2]; B = 8: the CLI's default batch) -- shape, source
+    split, on-load transform, residual, arithmetic -- and run each through the C ABI exactly as the network does (same
+    tile / split-K / kernel choice, which depend on B) against torch's fp32 convolution on the same device."""
     import torch.nn.functional as F
     from evc_amd import lib as L
     seen = {}
-    for B in (9, 32):
+    for B in (5, 6, 8, 9, 32):
         x = rnd(900, B, 15, 128, 128).cuda()
         c = rnd(901, B, 6, 128, 128).cuda()
         prof = []
@@ -124,7 +156,7 @@ def test_every_conv_launch_of_the_full_size_forward_against_torch(full_net):
         for r in prof:
             k = tuple(sorted(r["call"].items()))
             seen.setdefault(k, r["call"])
-    assert len(seen) > 80, len(seen)                       # 2 batch sizes x ~50 distinct layer configurations
+    assert len(seen) > 200, len(seen)                      # 5 batch sizes x ~50 distinct layer configurations
     worst = 0.0
     for n, call in enumerate(seen.values()):
         B, H, W, C0, C1, Co, K = (call[k] for k in ("B", "H", "W", "C0", "C1", "Co", "K"))
@@ -174,6 +206,21 @@ def test_full_size_ddpm_trajectory_against_reference_golden(full_net):
                                final_only=True, noise_fn=lambda i, x: noises[i])[0].cpu()
     assert rel(out.reshape(2, -1)[:, ::30].numpy(), g["samples"]) < 5e-4
     assert rel(out[:, :, 0, :].numpy(), g["first_row"]) < 5e-4
+
+
+def test_full_size_fpndm_trajectory_against_reference_golden(full_net):
+    """BASELINE configs[4]'s sampler at full size: F-PNDM, 10 subsampled steps = 3 Runge-Kutta warm-up iterations (4
+    forwards each, fractional midpoint labels) + 7 Adams-Bashforth ones = 19 full-size forwards, B=2, no noise, against
+    the reference sampler (models/__init__.py:39-100, models/pndm.py:3-52) run on the same weights and inputs."""
+    import evc_amd  # noqa: F401
+    from evc_amd import sampler
+    g = golden("traj_fpndm_full")
+    x_T, cond = rnd(821, 2, 15, 128, 128).cuda(), rnd(822, 2, 6, 128, 128).cuda()
+    out = sampler.FPNDM_sampler(x_T, full_net, cond=cond, subsample_steps=10, final_only=True, clip_before=True)[0].cpu()
+    assert rel(out.reshape(2, -1)[:, ::30].numpy(), g["samples"]) < 5e-4
+    assert rel(out[:, :, 0, :].numpy(), g["first_row"]) < 5e-4
+    st = g["stats"]
+    assert abs(float(out.std()) - float(st[1])) < 5e-4 * float(st[2])
 
 
 def test_sampler_trajectories_against_reference_goldens():
@@ -229,6 +276,49 @@ def test_hip_net_against_cpu_oracle_same_weights():
     net.preactivate = not net.preactivate
     out2 = net(x.cuda(), torch.tensor([120, 120, 120]), cond=cond.cuda())
     assert rel(out2, ref.numpy()) < 1e-4 and rel(out2, out.cpu().numpy()) < 2e-5
+
+
+def test_adversarial_adagn_rows_match_bf16x6_or_raise_the_range_flag():
+    """A trained checkpoint could carry AdaGN (1 + scale) rows far larger than seeded ones.  With every row scaled up the
+    fp16-split network must EITHER still agree with the exact bf16x6 network OR have raised EVC_RANGE_F16_OPERAND
+    (and then its output may be anything, including NaN -- never silently wrong finite numbers with a clean flag)."""
+    import os
+    import evc_amd  # noqa: F401
+    from evc_amd import lib as L
+    from evc_amd.scorenet import ScoreNet
+    from oracle.scorenet import Dims, seeded_params
+    d = Dims(ngf=32, n_head_channels=32, image_size=32)
+    p = seeded_params(d, 91)
+    x, cond = rnd(92, 2, 15, 32, 32).cuda(), rnd(93, 2, 6, 32, 32).cuda()
+    old = os.environ.get("EVC_CONV_ARITH")
+    try:
+        os.environ["EVC_CONV_ARITH"] = "f16x3"
+        n16 = ScoreNet(make_config(32, 32, 32), p)
+        os.environ["EVC_CONV_ARITH"] = "bf16x6"
+        n6 = ScoreNet(make_config(32, 32, 32), p)
+    finally:
+        if old is None:
+            os.environ.pop("EVC_CONV_ARITH", None)
+        else:
+            os.environ["EVC_CONV_ARITH"] = old
+    for n in (n16, n6):
+        n.prepare_labels([500.0])
+    base16, base6 = n16._table.clone(), n6._table.clone()
+    seen = set()
+    for factor in (1.0, 50.0, 3000.0, 1e6):
+        n16._table.copy_(base16 * factor)
+        n6._table.copy_(base6 * factor)
+        L.range_events(reset=True)
+        o16 = n16.forward_label(x, 500, cond)
+        ev = L.range_events(reset=True)
+        o6 = n6.forward_label(x, 500, cond)
+        L.range_events(reset=True)              # (the bf16x6 network shares the coefficient kernels: not its concern)
+        seen.add(bool(ev & L.RANGE_F16_OPERAND))
+        if not ev:
+            assert bool(torch.isfinite(o16).all()) and rel(o16, o6.cpu().numpy()) < 2e-4, factor
+        else:
+            assert ev & L.RANGE_F16_OPERAND, (factor, ev)
+    assert seen == {False, True}                # the seeded rows pass clean, the extreme ones are reported
 
 
 def test_graph_replay_equals_eager_launches():

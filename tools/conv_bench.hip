@@ -25,9 +25,7 @@ int main(int argc, char** argv) {
                                  {9, 32, 576, 576, 3, 1}, {9, 8, 768, 768, 1, 0}, {9, 64, 384, 192, 3, 1}};
     if (layout == 3) g_no_reuse = 1;          // A/B: bf16x6 without the row-reuse kernel
     if (layout == 4) g_wide_tiles = 0;        // A/B: row-reuse kernel with 128-pixel tiles only
-    if (layout == 6) g_no_2d = 1;             // A/B: row tiles (split arithmetics only) ...
-    if (layout == 5) g_no_2d = 0;             // ... against 2-D patch tiles
-    if (layout == 8) { g_no_2d = 1; g_tail_split = 0; }   // A/B: row tiles without the K-split tail
+    if (layout == 8) g_tail_split = 0;        // A/B: row tiles without the K-split tail
     printf("# conv_bench layout=%d iters=%d\n", layout, iters);
     if (layout == 2) {
         // sweep of (tile height, split factor) for the mid-size layers under bf16x6: prints the measured table
