@@ -17,8 +17,9 @@ forwards per chunk, fp32).  Weak scaling: every GPU decodes its own 9 clips; no 
 Synthetic data, seeded random weights of the reference architecture (no checkpoints / dataset offline).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
-  roofline     -- the dominant kernel family (implicit-GEMM convolution): algorithmic FLOPs per launch / average launch
-                  duration measured live with HIP events on the launch stream; `traffic` from the committed rocprofv3
+  roofline     -- the dominant kernel (one template instance of the implicit-GEMM convolution): algorithmic FLOPs per launch
+                  / its average launch duration measured live with HIP events recorded around that kernel on the launch
+                  stream; `rocprof` quotes the committed rocprofv3 --kernel-trace --stats CSV and `traffic` the committed
                   PMC passes when (and only when) they were taken on the kernel source that is running
   hbm_classes  -- achieved HBM rate of the memory-bound kernel classes, HIP-event timed at the
                   benchmark's shapes
@@ -76,6 +77,12 @@ def parse():
                     help="concurrent clip groups per GPU during generation (one HIP stream each)")
     ap.add_argument("--preactivate", action="store_true",
                     help="apply AdaGN+SiLU once per tensor in its own pass instead of inside the conv operand load")
+    ap.add_argument("--graphs", action="store_true",
+                    help="replay every score-network forward from a captured HIP graph (host enqueue 4.8 -> 0.2 ms per forward; "
+                         "same kernels, bit-identical results): for hosts whose CPU share per rank is small")
+    ap.add_argument("--fail-rank", type=int, default=-1,
+                    help="(plumbing test) this rank exits with an error before the first collective: the job must end "
+                         "non-zero within EVC_DIST_TIMEOUT_S instead of hanging")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0,
                     help="budget of EACH leg of the CPU baseline (all-threads forwards, 1-thread forward)")
@@ -101,6 +108,7 @@ def roofline_leg(net, clips, device):
     # 3x3 convolution; HIP events around concurrent launches would charge each with the other's time, so the profiled
     # forwards run the launches one after another on one stream
     overlap, net.overlap_skip = getattr(net, "overlap_skip", False), False
+    graphs, net.use_graphs = getattr(net, "use_graphs", False), False        # a graph replay makes no per-launch calls
     net.forward_label(x, 500, c)            # warm
     torch.cuda.synchronize()
     prof = []
@@ -110,14 +118,16 @@ def roofline_leg(net, clips, device):
         net.forward_label(x, 500, c)
     L.CONV_PROFILE = None
     torch.cuda.synchronize()
-    net.overlap_skip = overlap
+    net.overlap_skip, net.use_graphs = overlap, graphs
     per, kern = {}, {}
     mode_of = lambda c: (2 if c["act_in"] == L.ACT_SILU else 1) if c["coef"] else {L.ACT_SILU: 3, L.ACT_RELU: 4}.get(c["act_in"], 0)
     for r in prof:
+        # e0..ec brackets the convolution kernel alone (recorded inside the C call, before the split-K combine kernel):
+        # the duration rocprofv3 --kernel-trace reports for that kernel; e0..e1 includes the combine launch
+        ms_k, ms_all = r["e0"].elapsed_time(r["ec"]), r["e0"].elapsed_time(r["e1"])
         v = per.setdefault((r["arith"], r["variant"]), dict(n=0, ms=0.0, flops=0.0))
-        ms = r["e0"].elapsed_time(r["e1"])
         v["n"] += 1
-        v["ms"] += ms
+        v["ms"] += ms_all
         v["flops"] += r["flops"]
         # the kernel template instance this launch runs (csrc/conv_igemm.hip dispatch: row-reuse kernel for 3x3 filters on
         # whole-row tiles, simple-schedule kernel otherwise) -- the name rocprofv3 --kernel-trace --stats reports
@@ -130,74 +140,72 @@ def roofline_leg(net, clips, device):
         else:
             name = (f"conv_splitn_kernel<2, *, {r['variant']}, {mode_of(c)}>" if np_ == 2 else
                     f"conv_split_kernel<*, {r['variant']}, {mode_of(c)}>")
-        kv = kern.setdefault((name, r["arith"]), dict(n=0, ms=0.0, flops=0.0))
-        kv["n"] += 1; kv["ms"] += ms; kv["flops"] += r["flops"]
-    dom = max(per, key=lambda k: per[k]["ms"])
-    d = per[dom]
-    arith, tn = dom
-    name, peak, basis = ARITH_INFO[arith]
-    kname = {0: "conv_igemm_kernel", 1: "conv_split_rr_kernel<3>|conv_split_kernel",
-             2: "conv_split_rr_kernel<2>|conv_splitn_kernel<2>"}[arith] + f"<TN={tn}>"
-    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        kv = kern.setdefault((name, r["arith"]), dict(n=0, ms=0.0, ms_all=0.0, flops=0.0))
+        kv["n"] += 1; kv["ms"] += ms_k; kv["ms_all"] += ms_all; kv["flops"] += r["flops"]
     total_ms = sum(v["ms"] for v in per.values()) / reps
     total_flops = sum(v["flops"] for v in per.values()) / reps
-    # the single dominant kernel instance: frac = GFLOP per launch / average launch duration / peak, recomputable from the
-    # committed rocprofv3 --kernel-trace --stats CSV of the same forward (profiles/r03_forward_b9_kernel_stats.csv, taken
-    # with the side stream off like this leg; a split-K launch's HIP-event bracket here spans the combine kernel too)
+    # THE dominant kernel: the template instance with the largest share of the convolution time.  achieved = its algorithmic
+    # FLOPs per launch / its average launch duration (the kernel alone); the committed rocprofv3 --kernel-trace --stats CSV of
+    # the same forward (profiles/r03_forward_b9_kernel_stats.csv, side stream off like this leg) holds the same average.
     (dk_name, dk_arith), dk = max(kern.items(), key=lambda kv: kv[1]["ms"])
-    dk_peak = ARITH_INFO[dk_arith][1]
-    dk_us = dk["ms"] / dk["n"] * 1e3
-    dominant = {"name": dk_name, "launches_per_forward": dk["n"] // reps, "avg_us_hip_events": round(dk_us, 2),
-                "gflop_per_launch": round(dk["flops"] / dk["n"] / 1e9, 3),
-                "tflops": round(dk["flops"] / (dk["ms"] * 1e-3) / 1e12, 1),
-                "frac": round(dk["flops"] / (dk["ms"] * 1e-3) / 1e12 / dk_peak, 4), "peak": round(dk_peak, 1)}
+    aname, peak, basis = ARITH_INFO[dk_arith]
+    us = dk["ms"] / dk["n"] * 1e3
+    gflop = dk["flops"] / dk["n"] / 1e9
+    achieved = dk["flops"] / (dk["ms"] * 1e-3) / 1e12
+    out = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+           "frac": round(achieved / peak, 4), "traffic": None, "kernel": dk_name, "peak_basis": basis,
+           "launches_per_forward": dk["n"] // reps, "avg_launch_us": round(us, 2),
+           "algorithmic_gflop_per_launch": round(gflop, 3),
+           "avg_launch_us_incl_combine": round(dk["ms_all"] / dk["n"] * 1e3, 2),
+           "share_of_conv_time": round(dk["ms_all"] / reps / total_ms, 3),
+           "achieved_over_f32_mfma_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 3)}
     try:
         import csv
         meta = json.load(open(os.path.join(REPO, "profiles", "r03_forward_b9_kernel_stats.json")))
         if meta.get("source_sha") == source_sha() and meta.get("batch") == clips:
-            base, targs = dk_name.split("<")[0], dk_name.split("<")[1].rstrip(">")
             for row in csv.DictReader(open(os.path.join(REPO, "profiles", "r03_forward_b9_kernel_stats.csv"))):
-                if base + "<" + targs + ">" in row["Name"]:
-                    us = float(row["AverageNs"]) / 1e3
-                    dominant["avg_us_rocprof"] = round(us, 2)
-                    dominant["frac_rocprof"] = round(dominant["gflop_per_launch"] * 1e9 / (us * 1e-6) / 1e12 / dk_peak, 4)
-                    dominant["rocprof_csv"] = "profiles/r03_forward_b9_kernel_stats.csv"
+                if dk_name in row["Name"]:
+                    rus = float(row["AverageNs"]) / 1e3
+                    out["rocprof"] = {"csv": "profiles/r03_forward_b9_kernel_stats.csv", "avg_us": round(rus, 2),
+                                      "calls": int(row["Calls"]), "frac": round(gflop * 1e9 / (rus * 1e-6) / 1e12 / peak, 4)}
                     break
             if meta.get("held_clock_ghz"):
-                dominant["held_clock_ghz"] = meta["held_clock_ghz"]
-                dominant["frac_at_held_clock"] = round(dominant["frac"] * 2.4 / meta["held_clock_ghz"], 4)
+                out["held_clock_ghz"] = meta["held_clock_ghz"]
+                out["frac_at_held_clock"] = round(achieved / (peak * meta["held_clock_ghz"] / 2.4), 4)
+            if meta.get("mfma_busy_frac"):
+                out["mfma_busy_frac_pmc"] = meta["mfma_busy_frac"]
         else:
-            dominant["rocprof_note"] = (f"profiles/r03_forward_b9_kernel_stats.csv was taken on source "
-                                        f"{meta.get('source_sha')} at B={meta.get('batch')}: not quoted")
+            out["rocprof"] = (f"profiles/r03_forward_b9_kernel_stats.csv was taken on source {meta.get('source_sha')} at "
+                              f"B={meta.get('batch')}, this is {source_sha()} at B={clips}: not quoted")
     except Exception:
         pass
-    traffic, prov = None, "no rocprofv3 PMC profile committed for this kernel source"
+    prov = "no rocprofv3 PMC profile committed for this kernel source"
     try:       # HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, only if taken on THIS source
-        pmc = json.load(open(os.path.join(REPO, "profiles", f"r03_conv_{name}_pmc.json")))
+        pmc = json.load(open(os.path.join(REPO, "profiles", f"r03_conv_{aname}_pmc.json")))
         if pmc.get("source_sha") != source_sha():
-            prov = f"profiles/r03_conv_{name}_pmc.json is stale (taken on source {pmc.get('source_sha')}): not reported"
-        elif clips != pmc.get("batch"):
-            prov = f"profiles/r03_conv_{name}_pmc.json covers {pmc.get('kernel')} at B={pmc.get('batch')}"
+            prov = f"profiles/r03_conv_{aname}_pmc.json is stale (taken on source {pmc.get('source_sha')}): not reported"
+        elif clips != pmc.get("batch") or pmc.get("kernel") != dk_name:
+            prov = f"profiles/r03_conv_{aname}_pmc.json covers {pmc.get('kernel')} at B={pmc.get('batch')}"
         else:
-            traffic = pmc["hbm_bytes_per_launch"]
-            prov = f"profiles/r03_conv_{name}_pmc.json, source {pmc['source_sha']}, FETCH_SIZE x2 + WRITE_SIZE"
+            out["traffic"] = pmc["hbm_bytes_per_launch"]
+            prov = f"profiles/r03_conv_{aname}_pmc.json, source {pmc['source_sha']}, FETCH_SIZE x2 + WRITE_SIZE"
     except Exception:
         pass
-    by_family = {f"{ARITH_INFO[a][0]}<TN={t}>": {"launches_per_forward": v["n"] // reps,
-                                                 "ms_per_forward": round(v["ms"] / reps, 3),
-                                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
-                 for (a, t), v in sorted(per.items())}
-    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_provenance": prov,
-            "kernel": kname, "launches_per_forward": d["n"] // reps, "peak_basis": basis,
-            "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 2),
-            "algorithmic_gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 3),
-            "achieved_over_f32_mfma_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 3),
-            "conv_ms_per_forward": round(total_ms, 3),
-            "all_conv_tflops": round(total_flops / (total_ms * 1e-3) / 1e12, 2),
-            "dominant_kernel": dominant, "families": by_family, "batch": clips,
-            "overlap_note": "launch durations measured with the res-block side stream OFF (launches one after another); the "
-                            "timed region runs with it on"}
+    out["traffic_provenance"] = prov
+    out["conv_ms_per_forward"] = round(total_ms, 3)
+    out["all_conv_tflops"] = round(total_flops / (total_ms * 1e-3) / 1e12, 2)
+    out["kernels"] = {n: {"launches_per_forward": v["n"] // reps, "avg_us": round(v["ms"] / v["n"] * 1e3, 1),
+                          "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+                          "ms_per_forward_incl_combine": round(v["ms_all"] / reps, 3)}
+                      for (n, _), v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_all"])}
+    out["families"] = {f"{ARITH_INFO[a][0]}<TN={t}>": {"launches_per_forward": v["n"] // reps,
+                                                       "ms_per_forward": round(v["ms"] / reps, 3),
+                                                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
+                       for (a, t), v in sorted(per.items())}
+    out["batch"] = clips
+    out["note"] = ("launch durations measured with the res-block side stream OFF (launches one after another; the timed region "
+                   "runs with it on); `families` / conv_ms_per_forward include the split-K combine launches")
+    return out
 
 
 def hbm_classes_leg(clips, device):
@@ -342,6 +350,9 @@ def plumbing_only(a, D):
     if world != a.gpus:
         print(f"error: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         return 2
+    if rank == a.fail_rank:
+        print(f"rank {rank}: simulated failure (--fail-rank)", file=sys.stderr, flush=True)
+        os._exit(7)
     sd = {"w": torch.arange(1000, dtype=torch.float32)} if rank == 0 else None
     sd = D.broadcast_state_dict(sd, src=0, device=device, world=world)
     ok = bool((sd["w"].cpu() == torch.arange(1000, dtype=torch.float32)).all())
@@ -391,7 +402,7 @@ def main():
     sd_e = synthetic.elic_state_dict(3) if rank == 0 else None     # quality index 3 (q3)
     sd_d = D.broadcast_state_dict(sd_d, src=0, device=device, world=world)
     sd_e = D.broadcast_state_dict(sd_e, src=0, device=device, world=world)
-    net = ScoreNet(cfg, sd_d, device=device, preactivate=a.preactivate)
+    net = ScoreNet(cfg, sd_d, device=device, preactivate=a.preactivate, use_graphs=a.graphs)
     elic = ElicModel(sd_e, device=device)
     dec = ClipDecoder(net, elic, cfg, S.get_sampler(a.sampler), groups=a.groups)
 
@@ -456,7 +467,7 @@ def main():
                                   f"{a.clips} clips/GPU x 30 frames 128x128, q3, 2 ELIC key frames + "
                                   f"6 chunks x {fwd_per_chunk} forwards ({a.sampler}-{a.subsample}), B={a.clips} per launch",
                       "parallelism": f"clip-sharded dp{world}, no data-path collective; {a.groups} concurrent clip "
-                                     f"group(s) per GPU",
+                                     f"group(s) per GPU; forwards {'replayed from HIP graphs' if a.graphs else 'launched eagerly'}",
                       "weights": "seeded random, reference architecture (262.1M + ELIC)"},
            "per_rank_value": per_rank, "range_events": events,
            "whole_path_tflops_per_gpu": round(flop_per_step_gpu * a.steps / elapsed / 1e12, 2),

@@ -44,12 +44,15 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #ifndef EVC_SPLIT_WIDE_TILES
 #define EVC_SPLIT_WIDE_TILES 1 // 256-pixel / 8-wave form of the row-reuse kernel on grids of whole rounds (run-time option "wide_tiles")
 #endif
+#ifndef EVC_RR_PRIO
+#define EVC_RR_PRIO 0
+#endif
 #ifndef EVC_SPLIT_INTERLEAVE
 #define EVC_SPLIT_INTERLEAVE 5 // bf16x6 pipelined kernel: VALU instructions scheduled per MFMA in the second half (0 = compiler's order)
 #endif
 // Variants that were measured and did not pay -- 2-D patch tiles, a software-pipelined row-reuse loop, staging balance /
 // interleave switches, XCD-contiguous tile order, LDS-DMA of plain activation tiles, producer / consumer specialised kernels,
-// an in-kernel ("last-arriver") split-K combine, the ablation diagnostics behind profiles/r02_conv_bench_ablation*.log --
+// an in-kernel ("last-arriver") split-K combine, weight DMA issued mid-step, the ablation diagnostics behind profiles/r02_conv_bench_ablation*.log --
 // live in tools/experiments/, outside this file.
 
 namespace {
@@ -76,6 +79,13 @@ struct ConvK {
     // computed by tail_splits workgroups each (tail_sps K-steps per workgroup) that write raw partial sums to slabs of
     // tail_rows rows [tail_splits][tail_rows][Co]; blockIdx.x >= tail_first enumerates (tile, split) pairs.
     int tail_first, tail_splits, tail_sps, tail_rows;
+    // Fused 1x1 operand (row-reuse f16x3 kernel only): out += conv1x1(x2; w2).  x2 is a raw tensor (two sources like src),
+    // scaled from its element bound like in_bound; its products are accumulated FIRST, the accumulators are then rescaled
+    // by the exact power of two between the two operands' scales and the 3x3 K loop continues into them.
+    const float* x2_src0; const float* x2_src1; int x2_C0, x2_C1, x2_ld0, x2_ld1;
+    const char* x2_w;            // packed planes of the 1x1 weights (behind their header), nullptr = no fused operand
+    const float* x2_hdr;         // their header: [0] = 1 / (activation scale * weight scale)
+    const unsigned* x2_bound;
 };
 
 // f16x3 on a source with no GroupNorm in front of it (raw residual stream, attention output): the caller supplies a bound
@@ -918,6 +928,16 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kerne
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
+#if EVC_RR_PRIO
+    // EXPERIMENT: the two workgroups that share a CU get different static priorities (by the hardware wave slot their waves
+    // occupy on the SIMD), so that contention for the matrix pipe / issue slots is always resolved the same way and the
+    // favoured workgroup runs at its lone speed while the other fills the gaps -- instead of both running in lockstep.
+    {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (hwid & 1u) __builtin_amdgcn_s_setprio(EVC_RR_PRIO);
+    }
+#endif
 
     // K-split tail (ConvK::tail_*): blockIdx.x beyond the unsplit tiles enumerates (tile, split) pairs of the last tiles
     const bool tail = WM == 2 && (int)blockIdx.x >= p.tail_first;
@@ -1053,17 +1073,6 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kerne
     for (int o = tid * 16; o < 2 * NP * APL; o += NT * 16) *reinterpret_cast<float4*>(As + o) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
-    if (nmac > 0) {
-        chunk_setup();
-        load_coefs();
-        load_a();
-        dma_w(0);
-        store_a(0);
-        if (1 < nst) advance_w();
-    }
-    __syncthreads();
-
-    int wb = 0, sidx = 0;        // weight buffer of the current K-step, K-step index inside this split
 #define EVC_RR_TERMS(T0, T1)                                                                            \
     _Pragma("unroll") for (int t = T0; t < T1; ++t)                                                     \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)  \
@@ -1083,6 +1092,93 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kerne
 #define EVC_RR_NEXT_W()                                                                                 \
     dma_w(wb ^ 1);                              /* weights of K-step sidx + 1 */                        \
     if (sidx + 2 < nst) advance_w();
+
+    // ---- fused 1x1 operand (f16x3): out += conv1x1(x2).  One K-step per 16-channel chunk of x2: the tile's own pixels are
+    // staged plain (scaled from x2's element bound), the fragments are read at the centre tap of the staged image, the
+    // 1x1 weight slab arrives by LDS-DMA.  Double-buffered like the main loop, one barrier per chunk.  A split workgroup
+    // takes its share of the chunks.  Saves the separate 1x1 launch, its output write and the re-read as a residual. ----
+    if constexpr (NP == 2) {
+        if (p.x2_w) {
+            const int nch2 = (p.x2_C0 + p.x2_C1) / KC;
+            const int nsp = tail ? p.tail_splits : p.splits;
+            const int per = (nch2 + nsp - 1) / nsp;
+            const int c_begin = min(nch2, split * per), c_end = min(nch2, c_begin + per);
+            float s2 = 1.0f;
+            {
+                const float b = sqrtf(__uint_as_float(*p.x2_bound));
+                if (!(b < 3.0e38f)) s2 = __builtin_nanf("");
+                else if (b > 0.f) s2 = ldexpf(1.0f, 6 - ilogbf(b));
+            }
+            const float xscale2 = F16_ACT_SCALE * s2;
+            const bool pvalid = m0 + row < p.M;
+            const unsigned slab2 = (unsigned)NP * (unsigned)p.CoPad * RB;          // bytes per chunk of the 1x1 weights
+            float4 xr[2];
+            auto load2 = [&](int c) {
+                const int cc = c * KC;
+                const bool first = cc < p.x2_C0;
+                const char* src = reinterpret_cast<const char*>(first ? p.x2_src0 : p.x2_src1);
+                const unsigned ld = (unsigned)(first ? p.x2_ld0 : p.x2_ld1);
+                const unsigned o = ((unsigned)(pvalid ? m0 + row : 0) * ld + (unsigned)(first ? cc : cc - p.x2_C0) + 8u * kh) * 4u;
+                xr[0] = *reinterpret_cast<const float4*>(src + o);
+                xr[1] = *reinterpret_cast<const float4*>(src + o + 16);
+            };
+            auto store2 = [&](int ab) {
+                vec pl[NP];
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                SP::split(transform<MODE_PLAIN>(xr[0], z, z, pvalid), transform<MODE_PLAIN>(xr[1], z, z, pvalid), xscale2, pl);
+                char* A = As + ab * NP * APL + a_lds;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<vec*>(A + q * APL) = pl[q];
+            };
+            auto dma2 = [&](int wb2, int c) {
+                const char* wt = p.x2_w + (unsigned)c * slab2;
+                char* wl = Ws + wb2 * NP * BN * RB;
+                if (w_active) {
+#pragma unroll
+                    for (int j = 0; j < NWD; ++j)
+                        __builtin_amdgcn_global_load_lds((glb_void*)(wt + wsrc[j]), (lds_void*)(wl + wdst[j]), 16, 0, 0);
+                }
+            };
+            if (c_begin < c_end) {
+                load2(c_begin);
+                dma2(0, c_begin);
+                store2(0);
+            }
+            __syncthreads();
+            for (int c = c_begin; c < c_end; ++c) {
+                const int ab = (c - c_begin) & 1, wb = ab;
+                if (c + 1 < c_end) { dma2(ab ^ 1, c + 1); load2(c + 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                EVC_RR_FRAGS(1)
+                EVC_RR_TERMS(0, SP::NTERM / 2)
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + 1 < c_end) store2(ab ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                EVC_RR_TERMS(SP::NTERM / 2, SP::NTERM)
+                __syncthreads();
+            }
+            // both operands into one accumulator: bring the 1x1 partial sums to the 3x3 operand's scale (power of two: exact)
+            const float r = (p.x2_hdr[0] / s2) / (p.w_hdr[0] / in_scale(p));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] *= r;
+        }
+    }
+
+    if (nmac > 0) {
+        chunk_setup();
+        load_coefs();
+        load_a();
+        dma_w(0);
+        store_a(0);
+        if (1 < nst) advance_w();
+    }
+    __syncthreads();
+
+    int wb = 0, sidx = 0;        // weight buffer of the current K-step, K-step index inside this split
 
     for (int g = 0; g < nmac; ++g) {
         const int ab = g & 1;
@@ -1339,6 +1435,12 @@ static int conv_validate(const evc_conv_args* a) {
     if (a->ld_out < a->Co || (a->res && a->ld_res < a->Co)) return EVC_EINVAL;
     if ((long long)a->B * a->H * a->W > 0x7fffffffLL) return EVC_EINVAL;
     if (a->arith != EVC_ARITH_F32 && a->arith != EVC_ARITH_BF16X6 && a->arith != EVC_ARITH_F16X3) return EVC_EINVAL;
+    if (a->x2_w_packed) {       // fused 1x1 operand
+        if (!a->x2_src0 || !a->x2_bound || a->x2_C0 <= 0 || a->x2_C0 % KC != 0 || a->x2_C1 < 0 || a->x2_C1 % KC != 0) return EVC_EINVAL;
+        if (a->x2_C1 > 0 && !a->x2_src1) return EVC_EINVAL;
+        if ((a->x2_ld0 != 0 && (a->x2_ld0 < a->x2_C0 || (a->x2_ld0 & 3))) || (a->x2_ld1 != 0 && (a->x2_ld1 < a->x2_C1 || (a->x2_ld1 & 3))))
+            return EVC_EINVAL;
+    }
     return EVC_OK;
 }
 
@@ -1502,6 +1604,13 @@ extern "C" int evc_conv_set_option(const char* name, int value) {
     return EVC_EINVAL;
 }
 
+// The fused 1x1 operand exists in the f16x3 row-reuse kernel only (3x3 filters on tiles of whole image rows).
+extern "C" int evc_conv_fused_1x1_supported(const evc_conv_args* a) {
+    if (conv_validate(a) != EVC_OK) return 0;
+    if (a->arith != EVC_ARITH_F16X3 || a->KH != 3 || a->KW != 3) return 0;
+    return conv_tile_cfg(a).reuse == 1 ? 1 : 0;
+}
+
 extern "C" int evc_conv_choose_splits(const evc_conv_args* a) {
     if (conv_validate(a) != EVC_OK) return EVC_EINVAL;
     return conv_tile_cfg(a).splits;
@@ -1597,7 +1706,21 @@ static int launch_split_rr(int mode, dim3 grid, size_t lds, hipStream_t st, cons
 
 #define EVC_TN_SWITCH(tn, CALL) ((tn) == 3 ? CALL(3) : (tn) == 2 ? CALL(2) : CALL(1))
 
+static int conv2d_impl(const evc_conv_args* a, float* ws, void* stream, hipEvent_t ev_start, hipEvent_t ev_conv_end);
+
 extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stream) {
+    return conv2d_impl(a, ws, stream, nullptr, nullptr);
+}
+
+// Measurement hook (bench.py's roofline leg): the same launch, with `ev_start` recorded on the stream immediately before
+// the convolution kernel and `ev_conv_end` immediately after it -- i.e. BEFORE the split-K combine kernel, so the interval
+// is the convolution kernel's own duration, the number rocprofv3 --kernel-trace reports for it.  Either may be NULL.
+extern "C" int evc_conv2d_nhwc_profiled_f32(const evc_conv_args* a, float* ws, void* stream, void* ev_start,
+                                            void* ev_conv_end) {
+    return conv2d_impl(a, ws, stream, (hipEvent_t)ev_start, (hipEvent_t)ev_conv_end);
+}
+
+static int conv2d_impl(const evc_conv_args* a, float* ws, void* stream, hipEvent_t ev_start, hipEvent_t ev_conv_end) {
     int rc = conv_validate(a);
     if (rc != EVC_OK) return rc;
     int mode;
@@ -1640,6 +1763,19 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     if ((k.splits > 1 || cfg.tail_tiles) && !ws) return EVC_EINVAL;
     k.stats = k.splits > 1 ? nullptr : a->stats_out;   // with split-K the combine kernel writes them
     if (a->stats_out && evc_conv_stats_splits(a) == 0) return EVC_EINVAL;
+    k.x2_w = nullptr; k.x2_hdr = nullptr; k.x2_bound = nullptr; k.x2_src0 = k.x2_src1 = nullptr;
+    k.x2_C0 = k.x2_C1 = k.x2_ld0 = k.x2_ld1 = 0;
+    if (a->x2_w_packed) {
+        if (a->arith != EVC_ARITH_F16X3 || a->KH != 3 || a->KW != 3 || cfg.reuse != 1) return EVC_EUNSUPPORTED;
+        k.x2_src0 = a->x2_src0; k.x2_src1 = a->x2_src1 ? a->x2_src1 : a->x2_src0;
+        k.x2_C0 = a->x2_C0; k.x2_C1 = a->x2_C1;
+        k.x2_ld0 = a->x2_ld0 > 0 ? a->x2_ld0 : a->x2_C0;
+        k.x2_ld1 = a->x2_ld1 > 0 ? a->x2_ld1 : (a->x2_C1 > 0 ? a->x2_C1 : k.x2_ld0);
+        if ((long long)k.M * k.x2_ld0 * 4 >= (1LL << 32) || (long long)k.M * k.x2_ld1 * 4 >= (1LL << 32)) return EVC_EUNSUPPORTED;
+        k.x2_hdr = a->x2_w_packed;
+        k.x2_w = reinterpret_cast<const char*>(a->x2_w_packed) + F16_HDR_BYTES;
+        k.x2_bound = a->x2_bound;
+    }
     k.tail_first = 0x7fffffff; k.tail_splits = 1; k.tail_sps = 0; k.tail_rows = 0;
     if (cfg.tail_tiles) {
         k.tail_first = cfg.tail_first; k.tail_splits = cfg.tail_splits; k.tail_sps = cfg.tail_sps;
@@ -1649,6 +1785,7 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     dim3 grid((k.M + cfg.bm - 1) / cfg.bm, k.CoPad / cfg.bn, k.splits);
     if (cfg.tail_tiles) grid.x = cfg.tail_first + cfg.tail_tiles * cfg.tail_splits;
     hipStream_t st = (hipStream_t)stream;
+    if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return EVC_ELAUNCH;
     if (is_split_arith(a->arith)) {
         const int np = arith_planes(a->arith);
         if (cfg.reuse) {
@@ -1686,6 +1823,7 @@ extern "C" int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stre
     }
     if (rc != EVC_OK) return rc;
     if (hipGetLastError() != hipSuccess) return EVC_ELAUNCH;
+    if (ev_conv_end && hipEventRecord(ev_conv_end, st) != hipSuccess) return EVC_ELAUNCH;
     if (k.splits > 1) {
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((k.M + 63) / 64, (k.Co + 63) / 64), dim3(1024), 0, st, ws,
                            k.splits, k.M, k.Co, a->bias, a->res, a->ld_res, a->out_scale, a->act_out, a->out,

@@ -59,6 +59,11 @@ def init(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {"device_id": device} if backend == "nccl" else {}
+        # A rank that dies (or never arrives) must not leave the others waiting in a collective for ever: every collective
+        # gets a bounded wait (EVC_DIST_TIMEOUT_S, default 15 min -- longer than any timed region of the benchmark), after
+        # which the survivors raise; torchrun then tears the job down and exits non-zero.
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=float(os.environ.get("EVC_DIST_TIMEOUT_S", "900")))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, device
 

@@ -66,7 +66,9 @@ class ConvArgs(ctypes.Structure):
                 ("out_scale", c_float), ("act_out", c_int),
                 ("out", c_void_p), ("ld_out", c_int),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("Co", c_int), ("KH", c_int), ("KW", c_int),
-                ("splits", c_int), ("stats_out", c_void_p), ("arith", c_int), ("in_bound", c_void_p)]
+                ("splits", c_int), ("stats_out", c_void_p), ("arith", c_int), ("in_bound", c_void_p),
+                ("x2_src0", c_void_p), ("x2_src1", c_void_p), ("x2_C0", c_int), ("x2_C1", c_int), ("x2_ld0", c_int),
+                ("x2_ld1", c_int), ("x2_w_packed", c_void_p), ("x2_bound", c_void_p)]
 
 
 # name -> (restype, argtypes); exactly the symbols declared in include/evc_hip.h
@@ -112,9 +114,11 @@ HIP_SYMBOLS = {
     "evc_spade_act_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                        c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "evc_conv_choose_splits": (c_int, [POINTER(ConvArgs)]),
+    "evc_conv_fused_1x1_supported": (c_int, [POINTER(ConvArgs)]),
     "evc_conv_stats_splits": (c_int, [POINTER(ConvArgs)]),
     "evc_conv_workspace_bytes": (c_longlong, [POINTER(ConvArgs)]),
     "evc_conv2d_nhwc_f32": (c_int, [POINTER(ConvArgs), c_void_p, c_void_p]),
+    "evc_conv2d_nhwc_profiled_f32": (c_int, [POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_void_p]),
     "evc_attention_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                   c_float, c_void_p]),
     "evc_attention_workspace_bytes": (c_longlong, [c_int, c_int, c_int, c_int]),
@@ -471,10 +475,21 @@ def _src(s):
     return ptr(s), s.shape[-1], s.shape[-1], s.shape[:3]
 
 
+def conv_fused_1x1_supported(B, H, W, Ci, Co, arith, splits=0):
+    """Whether a 3x3 convolution of this shape may carry a fused 1x1 operand (``conv2d_nhwc(..., x2=)``): C query.  It
+    needs the f16x3 row-reuse kernel, i.e. 128-pixel tiles: very small grids, for which 64-pixel tiles are chosen, do not."""
+    d = c_void_p(16)
+    a = ConvArgs(d, None, Ci, 0, 0, 0, None, None, ACT_NONE, d, None, None, 0, 1.0, ACT_NONE, d, Co, B, H, W, Co, 3, 3, splits,
+                 None, arith, None)
+    return bool(hip_lib(require_device=False).evc_conv_fused_1x1_supported(ctypes.byref(a)))
+
+
 def conv2d_nhwc(src0, w_packed, Co, KH, KW, bias=None, src1=None, coef=None, act_in=ACT_NONE, res=None,
-                out_scale=1.0, act_out=ACT_NONE, out=None, splits=0, want_stats=False, in_bound=None):
+                out_scale=1.0, act_out=ACT_NONE, out=None, splits=0, want_stats=False, in_bound=None, x2=None):
     """out = act_out((conv(act_in(cat[src0,src1]*a+s), w) + bias + res) * out_scale); tensors are NHWC.
     ``src0`` / ``src1`` / ``out`` may be ``Cols`` channel slices of wider tensors.
+    ``x2 = (x2_src0, x2_src1 or None, w2_packed, bound)``: a fused 1x1 operand -- conv1x1(cat[x2_src0, x2_src1], w2) is
+    accumulated into the same output (include/evc_hip.h); ``bias`` must then be the sum of both convolutions' biases.
     ``want_stats=True`` returns ``(out, stats)``: per-channel moments of ``out`` in ``chan_stats`` layout, produced
     by the conv epilogue when the shape allows it, else by a separate ``evc_chan_stats_f32`` pass."""
     L = hip_lib()
@@ -491,6 +506,14 @@ def conv2d_nhwc(src0, w_packed, Co, KH, KW, bias=None, src1=None, coef=None, act
     a = ConvArgs(p0, p1, C0, C1, ld0, ld1, ptr(ca), ptr(cs), act_in, ptr(w_packed), ptr(bias), ptr(res),
                  0 if res is None else res.shape[-1], float(out_scale), act_out, po, ldo,
                  B, H, W, Co, KH, KW, splits, None, packed_arith(w_packed), _word(in_bound))
+    x2_ci = 0
+    if x2 is not None:
+        q0, qC0, qld0, qshp = _src(x2[0])
+        q1, qC1, qld1, _ = _src(x2[1])
+        assert tuple(qshp) == (B, H, W) and x2[2].dtype == torch.float16
+        a.x2_src0, a.x2_src1, a.x2_C0, a.x2_C1, a.x2_ld0, a.x2_ld1 = q0, q1, qC0, qC1, qld0, qld1
+        a.x2_w_packed, a.x2_bound = ptr(x2[2]), _word(x2[3])
+        x2_ci = qC0 + qC1
     stats = None
     if want_stats:
         ns = L.evc_conv_stats_splits(ctypes.byref(a))
@@ -502,19 +525,22 @@ def conv2d_nhwc(src0, w_packed, Co, KH, KW, bias=None, src1=None, coef=None, act
         raise EvcKernelError(f"evc_conv_workspace_bytes rejected the arguments ({nbytes})")
     ws = _workspace(nbytes, dev) if nbytes > 0 else None
     if CONV_PROFILE is not None:
+        # e0 .. ec: the convolution kernel alone (recorded inside the C call, before the split-K combine); e0 .. e1: with it
         st = torch.cuda.current_stream()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(st)
-    _check(L.evc_conv2d_nhwc_f32(ctypes.byref(a), ptr(ws), stream_ptr()), "evc_conv2d_nhwc_f32")
-    if CONV_PROFILE is not None:
+        e0, ec, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record(st); ec.record(st)          # (a torch event owns a hipEvent_t only once it has been recorded)
+        _check(L.evc_conv2d_nhwc_profiled_f32(ctypes.byref(a), ptr(ws), stream_ptr(), c_void_p(e0.cuda_event),
+                                              c_void_p(ec.cuda_event)), "evc_conv2d_nhwc_profiled_f32")
         e1.record(st)
-        CONV_PROFILE.append(dict(variant=conv_variant(Co), split=nbytes > 0, e0=e0, e1=e1, arith=a.arith,
-                                 flops=2.0 * B * H * W * Co * KH * KW * (C0 + C1),
+        CONV_PROFILE.append(dict(variant=conv_variant(Co), split=nbytes > 0, e0=e0, ec=ec, e1=e1, arith=a.arith,
+                                 flops=2.0 * B * H * W * Co * (KH * KW * (C0 + C1) + x2_ci),
                                  shape=(B, H, W, C0 + C1, Co, KH),
                                  call=dict(B=B, H=H, W=W, C0=C0, C1=C1, Co=Co, K=KH, coef=coef is not None, act_in=act_in,
                                            res=res is not None, out_scale=float(out_scale), bias=bias is not None,
                                            bound=in_bound is not None, arith=a.arith, ld_out=ldo,
-                                           stats=bool(want_stats))))
+                                           stats=bool(want_stats), x2=x2_ci)))
+    else:
+        _check(L.evc_conv2d_nhwc_f32(ctypes.byref(a), ptr(ws), stream_ptr()), "evc_conv2d_nhwc_f32")
     result = out.t if isinstance(out, Cols) else out
     if want_stats:
         return result, (stats if stats is not None else chan_stats(result))

@@ -104,12 +104,17 @@ class _Job:
 
 
 def run_policy(decoder, models, clips, qs, thresholds, metric, patch=64, frames=30, max_batch=32, seed=0,
-               bpp_limit=1.0, device="cuda", log=None):
+               bpp_limit=1.0, device="cuda", log=None, noise_source=None, stats=None):
     """The reference's sweep, batched.
 
     decoder:       ClipDecoder (only ``generate`` is used: the generator does not depend on q)
     models:        q -> ElicModel
     clips:         {vid: float tensor (frames, 3, H, W) in [0, 1]} (host)
+    noise_source:  optional ``fn(job, round, step, shape) -> tensor`` (job = (vid, q, thr); step 0 = x_T, step i+1 = the
+                   noise of sampler step i) replacing the per-job device generators -- parity tests inject the noise the
+                   CPU oracle loop uses
+    stats:         optional dict, filled with the launch-size histogram {batch size: generation launches}, the number of
+                   generation rounds and of key frames coded
     Returns {(vid, q): [dict(thr, x (frames,3,H,W) float32 numpy, d (frames,) int, bits [..], bpp)]} with, per (vid, q),
     the thresholds in the given order cut at the first one whose rate reaches ``bpp_limit`` bits per pixel
     (``if NN_bpp >= 1.0: break``, city_sender.py:563-564)."""
@@ -147,6 +152,10 @@ def run_policy(decoder, models, clips, qs, thresholds, metric, patch=64, frames=
         def fn(tag, shape):      # one counter-based stream per (job, round, step): independent of the batch composition
             step = 0 if tag == "init" else int(tag) + 1
             out = torch.empty(shape, device=device, dtype=torch.float32)
+            if noise_source is not None:
+                for i, j in enumerate(batch):
+                    out[i] = noise_source((j.vid, j.q, j.thr), j.round, step, tuple(shape[1:])).to(device)
+                return out
             for i, j in enumerate(batch):
                 g = torch.Generator(device=device)
                 g.manual_seed(((((int(seed) & 0xFFFFF) << 20 | j.uid) << 6 | j.round) << 10 | step) & (2 ** 63 - 1))
@@ -163,6 +172,9 @@ def run_policy(decoder, models, clips, qs, thresholds, metric, patch=64, frames=
             batch = active[c0:c0 + max_batch]
             cond = torch.stack([torch.stack(j.x[-2:], 0) for j in batch], 0).contiguous()     # (n, 2, 3, H, W)
             pred = decoder.generate(cond, noise_fn=noise_for(batch), groups=1)              # (n, 5, 3, H, W)
+            if stats is not None:
+                h = stats.setdefault("launch_sizes", {})
+                h[len(batch)] = h.get(len(batch), 0) + 1
             n_new = [min(pred.shape[1], frames - len(j.x)) for j in batch]
             flat_p = torch.cat([pred[k, :n_new[k]] for k in range(len(batch))], 0)
             flat_g = torch.cat([gt_dev[j.vid][len(j.x):len(j.x) + n_new[k]] for k, j in enumerate(batch)], 0)
@@ -182,6 +194,9 @@ def run_policy(decoder, models, clips, qs, thresholds, metric, patch=64, frames=
             ensure_keys({(j.vid, j.q, f) for j in fallback for f in (len(j.x), len(j.x) + 1) if f < frames})
             for j in fallback:
                 add_keys(j, [f for f in (len(j.x), len(j.x) + 1) if f < frames])
+        if stats is not None:
+            stats["rounds"] = stats.get("rounds", 0) + 1
+            stats["key_frames_coded"] = len(key_cache)
         if log is not None:
             log(f"policy round: {len(active)} active jobs, {len(fallback)} fell back to key frames")
 

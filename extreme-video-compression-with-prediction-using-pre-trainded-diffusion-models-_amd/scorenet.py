@@ -153,6 +153,9 @@ class ScoreNet:
         # the x-branch of a res-block (1x1 skip convolution) on a side stream, overlapped with the h-branch
         import os
         self.overlap_skip = os.environ.get("EVC_OVERLAP_SKIP", "1") != "0"
+        # a res-block's 1x1 skip convolution (Conv_2) as extra K-steps of its Conv_1 launch (one accumulator, no separate
+        # launch / output / residual re-read): f16x3 row-reuse kernel only, EVC_FUSE_SKIP=0 restores the separate launches
+        self.fuse_skip = self._f16_raw and os.environ.get("EVC_FUSE_SKIP", "1") != "0"
         self._side_streams = {}
         self._bounds_by_stream = {}      # concurrent clip groups run forwards on their own streams: one arena each
         self._bounds = None
@@ -204,6 +207,7 @@ class ScoreNet:
                     # 1x1 skip convolution on the raw residual stream: fp16 split too, scaled by the element bound that
                     # the block's own GroupNorm moments give (gn_coeffs(..., bound=))
                     e["w2"] = self._pack_conv(g(n + ".Conv_2.weight"), bounded=True); e["b2"] = self._dev(g(n + ".Conv_2.bias"))
+                    e["b12"] = (e["b1"] + e["b2"]).contiguous()      # bias of Conv_1 with Conv_2 fused into it
                 self.w[i] = e
             elif k == "attn":
                 ws = [g(f"{n}.NIN_{j}.W") for j in range(4)]   # (in, out): conv weight is the transpose
@@ -313,18 +317,24 @@ class ScoreNet:
                 return L.conv2d_nhwc(src, e["w2"], m["cout"], 1, 1, bias=e["b2"], src1=src1, in_bound=xbound, out=out)
             return src
 
+        Ho, Wo = (2 * H, 2 * W) if m["up"] else ((H // 2, W // 2) if m["down"] else (H, W))
+        fuse = self.fuse_skip and "w2" in e and not self.preactivate and \
+            L.conv_fused_1x1_supported(B, Ho, Wo, m["cout"], m["cout"], L.packed_arith(e["w1"]))
         # The x-branch only depends on the block input: with `overlap_skip` it runs on a side stream while the main stream
         # does the h-branch (FIR, Conv_0, its moments), so its small latency-bound launches (the 1x1 convolution, its
         # split-K combine) hide behind Conv_0 instead of sitting in front of Conv_1.  Joined by an event before Conv_1.
+        # With `fuse` only the FIR of an up / down block is left of it (the 1x1 convolution rides in Conv_1's launch).
         side = done = xs = None
-        if self.overlap_skip and "w2" in e:
+        if self.overlap_skip and "w2" in e and (not fuse or fir is not None):
             main = torch.cuda.current_stream()
             side = self._side_stream(main)
-            Ho, Wo = (2 * H, 2 * W) if m["up"] else ((H // 2, W // 2) if m["down"] else (H, W))
-            xs = torch.empty((B, Ho, Wo, m["cout"]), device=self.device, dtype=torch.float32)   # owned by the main stream
+            xs = torch.empty((B, Ho, Wo, m["cin"] if fuse else m["cout"]), device=self.device, dtype=torch.float32)   # owned by the main stream
             side.wait_stream(main)                # coef0's launch raised the bound word; x / skip are complete
             with torch.cuda.stream(side):
-                skip_path(xs)
+                if fuse:
+                    L.upfirdn2d_nhwc(x.t, *fir, out=xs)
+                else:
+                    skip_path(xs)
                 done = torch.cuda.Event()
                 done.record(side)
         if fir is not None:
@@ -344,9 +354,18 @@ class ScoreNet:
         H1, W1 = h1.t.shape[1], h1.t.shape[2]
         coef1 = self._adagn([h1.stats()], H1 * W1, m["cout"], e["ss1"], rows)
         if side is None:
-            xs = skip_path(None)
+            if fuse:
+                xs = L.upfirdn2d_nhwc(x.t, *fir) if fir is not None else None
+            else:
+                xs = skip_path(None)
         else:
             torch.cuda.current_stream().wait_event(done)
+        if fuse:
+            # Conv_1 + Conv_2 in one launch (models/better/layerspp.py:603-624): x2 = the block input (both halves of a skip
+            # concat read in place) or its FIR-resampled copy; |FIR(x)| <= max |x| (taps sum to 1), so x's bound serves both
+            x2 = (xs, None, e["w2"], xbound) if xs is not None else (x.t, s1, e["w2"], xbound)
+            return _Act(*L.conv2d_nhwc(h1.t, e["w1"], m["cout"], 3, 3, bias=e["b12"], coef=coef1, act_in=L.ACT_SILU,
+                                       out_scale=INV_SQRT2, want_stats=True, x2=x2))
         if self.preactivate:
             h1a = L.affine_act(h1.t, coef1, L.ACT_SILU)
             return _Act(*L.conv2d_nhwc(h1a, e["w1"], m["cout"], 3, 3, bias=e["b1"], res=xs, out_scale=INV_SQRT2,

@@ -167,6 +167,17 @@ typedef struct {
                               the sources by the power of two that brings sqrt(S) into [64, 128) before the fp16 split and
                               the accumulator by its inverse: lets the fp16 arithmetic take inputs that no GroupNorm has
                               normalised (1x1 skip convolutions, NIN output projections). */
+    /* Optional FUSED 1x1 OPERAND (x2_w_packed != NULL; only where evc_conv_fused_1x1_supported() says so: EVC_ARITH_F16X3,
+     * 3x3 filters on the row-reuse kernel):
+     *     out = act_out((conv(act_in(cat[src0,src1]*a+s), w) + conv1x1(cat[x2_src0,x2_src1], x2_w) + bias + res) * out_scale)
+     * = a res-block's Conv_1 plus its 1x1 skip convolution Conv_2 on the block input (reference
+     * models/better/layerspp.py:603-624: x = Conv_2(x); return (x + h) / sqrt(2)) in ONE launch and one accumulator:
+     * x2's K-steps run first, the accumulators are rescaled by the (power-of-two) ratio of the two operands' scales, the
+     * 3x3 K loop continues into them.  x2 is a raw tensor of the output's B x H x W (two sources like src, row strides
+     * x2_ld*, 0 = C), x2_w_packed its [Co][x2_C0+x2_C1][1][1] weights packed for EVC_ARITH_F16X3, x2_bound its element
+     * bound (as in_bound, required).  `bias` must already hold the sum of both convolutions' biases. */
+    const float* x2_src0; const float* x2_src1; int x2_C0; int x2_C1; int x2_ld0; int x2_ld1;
+    const float* x2_w_packed; const unsigned* x2_bound;
 } evc_conv_args;
 int evc_conv_co_pad(int Co);
 long long evc_conv_packed_floats(int Co, int Ci, int KH, int KW);
@@ -183,12 +194,17 @@ int evc_conv_pack_weights(const float* w, void* packed, int Co, int Ci, int KH, 
  * Returns EVC_EINVAL for an unknown name. */
 int evc_conv_set_option(const char* name, int value);
 int evc_conv_choose_splits(const evc_conv_args* a);
+int evc_conv_fused_1x1_supported(const evc_conv_args* a);   /* 1: these arguments may carry the fused 1x1 operand */
 /* The number of pixel runs per image (H*W/64 or H*W/32) for which the fused moments will be written, when they are
  * available for these arguments (H*W % 64 == 0 and either split-K -- the combine kernel writes them -- or only full
  * tiles), else 0: the caller then runs evc_chan_stats_f32 on the output instead. */
 int evc_conv_stats_splits(const evc_conv_args* a);
 long long evc_conv_workspace_bytes(const evc_conv_args* a);
 int evc_conv2d_nhwc_f32(const evc_conv_args* a, float* ws, void* stream);
+/* Measurement hook: the same launch with two hipEvent_t handles (either may be NULL) recorded on `stream` immediately before
+ * the convolution kernel and immediately after it, i.e. before the split-K combine kernel: the interval is the convolution
+ * kernel's own duration, the figure rocprofv3 --kernel-trace reports for it (bench.py's roofline leg). */
+int evc_conv2d_nhwc_profiled_f32(const evc_conv_args* a, float* ws, void* stream, void* ev_start, void* ev_conv_end);
 
 /* ---- multi-head spatial self-attention ------------------------------------------------------
  * out[b][n][h*D + d] = sum_m softmax_m(q[b][n][h].k[b][m][h] * scale) * v[b][m][h][d]

@@ -89,6 +89,18 @@ def test_bench_gpus2_launches_two_ranks_itself():
     assert line["backend"] == "gloo" and line["broadcast_ok"] is True
 
 
+def test_a_failed_rank_ends_the_job_non_zero_in_bounded_time():
+    """One rank dies before the first collective: the launcher must come back non-zero (torchrun tears the job down; the
+    surviving rank's collective has a bounded wait, EVC_DIST_TIMEOUT_S) -- never a hang, never a result line."""
+    import time
+    t0 = time.time()
+    rc, line, err = _run_bench(["--gpus", "2", "--plumbing-only", "--fail-rank", "1"],
+                               {"EVC_DIST_BACKEND": "gloo", "EVC_DIST_TIMEOUT_S": "30"}, timeout=200)
+    assert rc != 0 and line is None, (rc, line)
+    assert time.time() - t0 < 150
+    assert "simulated failure" in err
+
+
 def test_bench_refuses_world_size_mismatch():
     rc, line, err = _run_bench(["--gpus", "2", "--plumbing-only"], {"EVC_DIST_BACKEND": "gloo", "WORLD_SIZE": "1", "RANK": "0"})
     assert rc == 2 and line is None and "WORLD_SIZE=1" in err

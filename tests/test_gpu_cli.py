@@ -4,6 +4,9 @@ import os
 
 import numpy as np
 import pytest
+import torch
+
+from conftest import rnd
 
 pytestmark = pytest.mark.gpu
 
@@ -141,3 +144,76 @@ def test_batched_policy_sweep_equals_one_job_at_a_time():
     env = P.rd_envelope([r["bpp"] for r in many[(0, 3)]], [np.mean([P.cal_psnr(r["x"][t], clips[0][t].numpy())
                                                                      for t in range(30)]) for r in many[(0, 3)]], True)
     assert env.shape[0] == 2 and 1 <= env.shape[1] <= len(many[(0, 3)])
+
+
+def test_policy_sweep_against_the_oracle_sender_loop():
+    """SURVEY.md 8f item 2 against an ORACLE (not against itself): ``policy.run_policy`` -- every (video, threshold) job
+    batched into shared launches -- must make the decisions of the reference's one-job-at-a-time loop
+    (city_sender.py:495-607, restated in oracle/pipeline.py::run_clip on the CPU oracle's ELIC + score network + DDPM
+    sampler) when both draw the same injected noise: same transmit masks, same key-frame bit counts, frames within the
+    fp32 sampler tolerance.  Thresholds are picked from the oracle's own PSNR trace, away from every value the rule
+    compared against, so a 1e-4 difference between the two implementations cannot flip a decision."""
+    import evc_amd  # noqa: F401
+    from evc_amd import policy as P, sampler as S, synthetic
+    from evc_amd.config import default_config
+    from evc_amd.decoder import ClipDecoder
+    from evc_amd.elic import ElicModel
+    from evc_amd.scorenet import ScoreNet
+    from oracle import pipeline as OP, scorenet as ON
+    from test_oracle_pipeline import NativeCoder
+    size, frames, subsample = 64, 12, 2
+    d_net = ON.Dims(ngf=32, n_head_channels=32, image_size=size)
+    p_net = ON.seeded_params(d_net, 9)
+    p_elic = synthetic.elic_state_dict(3)
+    clips = synthetic.make_clips(2, seed=0, frames=frames, size=size).astype(np.float64) / 255.0
+
+    def noise(job, rnd_no, step, shape):            # pure function of (video, round, step): both loops call it
+        vid = job[0] if isinstance(job, tuple) else job
+        return rnd(7000 + 1000 * int(vid) + 16 * int(rnd_no) + int(step), *shape)
+
+    def oracle_job(vid, thr, trace=None):
+        fn = lambda tag, shape: noise(vid, tag[0], 0 if tag[1] == "init" else int(tag[1]) + 1, shape[1:]).reshape(shape)
+        return OP.run_clip(p_net, d_net, p_elic, torch.from_numpy(clips[vid]), threshold=thr, subsample=subsample,
+                           noise_fn=fn, coder=NativeCoder, frames=frames, trace=trace)
+    # a threshold in the widest gap of the PSNR values the rule meets when everything is accepted
+    tr = []
+    for vid in (0, 1):
+        oracle_job(vid, -100.0, tr)
+    v = np.sort(np.asarray(tr))
+    gaps = np.diff(v)
+    mids = [float(v[k] + gaps[k] / 2) for k in np.argsort(gaps)[-3:]]          # the three widest gaps
+    thresholds = [-100.0] + sorted(mids) + [200.0]
+    cfg = default_config(32, 32, size, subsample=subsample)
+    net = ScoreNet(cfg, p_net)
+    elic = ElicModel(p_elic)
+    dec = ClipDecoder(net, elic, cfg, S.get_sampler("DDPM"))
+    stats = {}
+    res = P.run_policy(dec, {3: elic}, {vid: torch.from_numpy(clips[vid]).float() for vid in (0, 1)}, [3], thresholds,
+                       P.PsnrMetric(), patch=64, frames=frames, max_batch=4, noise_source=noise, stats=stats)
+    assert sum(stats["launch_sizes"].values()) >= 2 and max(stats["launch_sizes"]) > 1      # jobs really shared launches
+    seen_masks, compared, cut = set(), 0, 0
+    for vid in (0, 1):
+        got = {r["thr"]: r for r in res[(vid, 3)]}
+        for thr in thresholds:
+            trace = []
+            ref = oracle_job(vid, thr, trace)
+            if min(abs(t - thr) for t in trace) < 0.02:
+                continue                                    # a tie within 0.02 dB: not a fair comparison point
+            if ref["bpp"] >= 1.0:
+                assert thr not in got                       # the sweep is cut at 1 bit per pixel (city_sender.py:563-564)
+                cut += 1
+                continue
+            g = got[thr]
+            np.testing.assert_array_equal(g["d"], ref["d"])
+            assert g["bits"] == ref["bits"], (vid, thr)
+            # key frames are the codec's output for the same symbols; generated frames are conditioned on each loop's OWN
+            # earlier output, so fp32-level differences compound from chunk to chunk: tight on the first chunk, PSNR after
+            diff = np.abs(g["x"] - ref["x"].numpy())
+            first_gen = int(np.argmax(g["d"] == 0)) if (g["d"] == 0).any() else frames
+            assert float(diff[:min(frames, first_gen + 5)].max()) < 5e-3      # (the two loops' key frames differ by <= 5e-4)
+            assert 10 * np.log10(1.0 / max(float((diff.astype(np.float64) ** 2).mean()), 1e-30)) > 50.0
+            seen_masks.add(tuple(int(t) for t in g["d"]))
+            compared += 1
+    # both videos' all-accepting jobs were compared, and the sweep held rejecting thresholds too (other masks, or jobs the
+    # 1-bit-per-pixel rule cut in BOTH implementations)
+    assert compared >= 2 and (len(seen_masks) >= 2 or cut >= 2), (compared, cut, seen_masks)

@@ -221,6 +221,62 @@ def test_conv_split_k_is_deterministic_and_matches_unsplit(L, arith, B, H, W, C0
         L.conv_set_option("no_such_option", 1)
 
 
+@pytest.mark.parametrize("B,H,W,C,Co,C2a,C2b,splits", [
+    (9, 32, 32, 192, 192, 96, 32, 0),     # concat second operand (two sources); split-K chosen automatically
+    (9, 32, 32, 64, 192, 48, 0, 3),       # fixed 3-way split-K: every split takes its share of the 1x1 chunks
+    (9, 8, 8, 384, 384, 160, 0, 0),       # W = 8 (a tile spans two images), two channel tiles, partial last pixel tile
+    (9, 16, 16, 192, 384, 64, 64, 0),     # W = 16, two channel tiles, two sources
+    (5, 128, 128, 96, 192, 64, 0, 0),     # 640 tiles: one round + a K-split tail
+    (8, 64, 64, 64, 128, 16, 0, 0),       # unsplit, a single 1x1 chunk, 128-wide channel tile
+])
+def test_conv3x3_with_fused_1x1_operand(L, B, H, W, C, Co, C2a, C2b, splits):
+    """A res-block's Conv_1 (3x3 on GroupNorm + SiLU of h) and its skip convolution Conv_2 (1x1 on the raw block input, which
+    may be a concat) in ONE launch and one accumulator (evc_conv_args.x2_*; reference models/better/layerspp.py:603-624:
+    (Conv_2(x) + Conv_1(act(h))) / sqrt(2)).  Against torch; against the two separate launches it replaces; with a second
+    operand 1e4 times larger / smaller than the first (the accumulator rescaling between the operands is exact)."""
+    assert L.conv_fused_1x1_supported(B, H, W, C, Co, L.ARITH_F16X3, splits)
+    assert not L.conv_fused_1x1_supported(B, H, W, C, Co, L.ARITH_BF16X6, splits)
+    assert not L.conv_fused_1x1_supported(1, 8, 8, C, Co, L.ARITH_F16X3)        # tiny grid: 64-pixel tiles, no row-reuse kernel
+    h = nhwc(rnd(60, B, C, H, W).cuda())
+    a, s = (1 + 0.2 * rnd(61, B, C)).cuda(), (0.3 * rnd(62, B, C)).cuda()
+    w1 = (rnd(63, Co, C, 3, 3) / np.sqrt(9 * C)).cuda()
+    b1, b2 = rnd(64, Co).cuda(), rnd(65, Co).cuda()
+    C2 = C2a + C2b
+    w2 = (rnd(66, Co, C2, 1, 1) / np.sqrt(C2)).cuda()
+    wp1, wp2 = L.conv_pack_weights(w1, L.ARITH_F16X3), L.conv_pack_weights(w2, L.ARITH_F16X3)
+    for mag in (1.0, 1e4, 1e-4):
+        xa = nhwc(rnd(67, B, C2a, H, W).cuda()) * mag
+        xb = nhwc(rnd(68, B, C2b, H, W).cuda()) * (2 * mag) if C2b else None
+        bound = torch.zeros(1, dtype=torch.int32, device="cuda")
+        L.gn_coeffs([L.chan_stats(xa)] + ([L.chan_stats(xb)] if C2b else []), H * W, 16, 1e-5, bound=bound)
+        fused, st = L.conv2d_nhwc(h, wp1, Co, 3, 3, bias=b1 + b2, coef=(a, s), act_in=L.ACT_SILU, out_scale=0.70710678,
+                                  splits=splits, want_stats=True, x2=(xa, xb, wp2, bound))
+        xcat = torch.cat([xa, xb], 3) if C2b else xa
+        ref = (F.conv2d(silu_affine(nchw(h), a, s).double(), w1.double(), b1.double(), padding=1) +
+               F.conv2d(nchw(xcat).double(), w2.double(), b2.double())) * 0.70710678
+        assert float((nchw(fused).double() - ref).abs().max() / ref.abs().max()) < 3e-6, mag
+        o = fused.double().reshape(B, H * W, Co)
+        assert rel(st.double().sum(1).float(), torch.stack([o.sum(1), (o * o).sum(1)], -1).float()) < 1e-5
+        skip = L.conv2d_nhwc(xa, wp2, Co, 1, 1, bias=b2, src1=xb, in_bound=bound)           # the two launches it replaces
+        two = L.conv2d_nhwc(h, wp1, Co, 3, 3, bias=b1, coef=(a, s), act_in=L.ACT_SILU, res=skip, out_scale=0.70710678,
+                            splits=splits)
+        assert rel(fused, two) < 3e-6, mag
+        again, _ = L.conv2d_nhwc(h, wp1, Co, 3, 3, bias=b1 + b2, coef=(a, s), act_in=L.ACT_SILU, out_scale=0.70710678,
+                                 splits=splits, want_stats=True, x2=(xa, xb, wp2, bound))
+        assert torch.equal(again, fused)
+    # a NaN in the second operand: its bound is the NaN pattern, the whole output is NaN (never finite garbage)
+    xn = xa.clone()
+    xn[0, 1, 1, 3] = float("nan")
+    bound.zero_()
+    L.gn_coeffs([L.chan_stats(xn)] + ([L.chan_stats(xb)] if C2b else []), H * W, 16, 1e-5, bound=bound)
+    bad = L.conv2d_nhwc(h, wp1, Co, 3, 3, bias=b1 + b2, coef=(a, s), act_in=L.ACT_SILU, splits=splits, x2=(xn, xb, wp2, bound))
+    assert not bool(torch.isfinite(bad).any())
+    L.range_events(reset=True)
+    # where the fused operand is not available the call is refused, never silently ignored
+    with pytest.raises(L.EvcKernelError):
+        L.conv2d_nhwc(h, L.conv_pack_weights(w1, L.ARITH_BF16X6), Co, 3, 3, bias=b1, x2=(xa, xb, wp2, bound))
+
+
 def test_conv_bf16x6_is_not_less_accurate_than_f32_mfma(L):
     """The precision claim of EVC_ARITH_BF16X6 and EVC_ARITH_F16X3, on the real kernels: against an fp64 reference
     their error is no larger than that of the exact-product f32 MFMA path (all accumulate in fp32), for the dominant

@@ -177,8 +177,16 @@ def test_every_conv_launch_of_the_full_size_forward_against_torch(full_net):
                         bound=bound)
         wp = L.conv_pack_weights(w, call["arith"])
         out = torch.empty(B, H, W, call["ld_out"], device="cuda")
+        x2 = x2t = w2 = None
+        if call.get("x2"):           # a res-block's 1x1 skip convolution fused into its Conv_1 launch
+            C2 = call["x2"]
+            x2t = 3.0 * torch.randn(B, H, W, C2, device="cuda", generator=g)
+            w2 = torch.randn(Co, C2, 1, 1, device="cuda", generator=g) / np.sqrt(C2)
+            b2 = torch.zeros(1, dtype=torch.int32, device="cuda")
+            L.gn_coeffs([L.chan_stats(x2t)], H * W, 32 if C2 % 32 == 0 else 1, 1e-5, bound=b2)
+            x2 = (x2t, None, L.conv_pack_weights(w2, L.ARITH_F16X3), b2)
         got = L.conv2d_nhwc(x0, wp, Co, K, K, bias=bias, src1=x1, coef=coef, act_in=call["act_in"], res=res,
-                            out_scale=call["out_scale"], out=out, in_bound=bound, want_stats=call["stats"])
+                            out_scale=call["out_scale"], out=out, in_bound=bound, want_stats=call["stats"], x2=x2)
         got = got[0] if call["stats"] else got
         xin = torch.cat([x0, x1], 3) if C1 else x0
         if coef is not None:
@@ -186,6 +194,8 @@ def test_every_conv_launch_of_the_full_size_forward_against_torch(full_net):
         if call["act_in"] == L.ACT_SILU:
             xin = F.silu(xin)
         ref = F.conv2d(xin.permute(0, 3, 1, 2), w, bias, padding=K // 2).permute(0, 2, 3, 1)
+        if x2 is not None:
+            ref = ref + F.conv2d(x2t.permute(0, 3, 1, 2), w2).permute(0, 2, 3, 1)
         if res is not None:
             ref = ref + res
         ref = ref * call["out_scale"]

@@ -30,10 +30,11 @@ int main(int argc, char** argv) {
     if (layout == 2) {
         // sweep of (tile height, split factor) for the mid-size layers under bf16x6: prints the measured table
         struct S2 { int R, Ci, Co, K; };
-        const S2 ss[] = {{64, 192, 192, 3}, {64, 384, 192, 3}, {64, 384, 384, 3}, {32, 384, 384, 3}, {32, 576, 576, 3},
+        const S2 ss[] = {{128, 192, 192, 3}, {128, 384, 192, 3}, {64, 192, 192, 3}, {64, 384, 192, 3}, {64, 384, 384, 3}, {32, 384, 384, 3}, {32, 576, 576, 3},
                          {16, 576, 576, 3}, {16, 768, 768, 3}, {8, 768, 768, 3}, {8, 1536, 768, 3}, {32, 384, 1152, 1},
                          {16, 576, 1728, 1}, {8, 768, 2304, 1}, {8, 768, 768, 1}, {16, 576, 576, 1}};
-        const int Bs[] = {9};
+        std::vector<int> Bs;                       // 5th argument: comma-separated batch sizes of the sweep (default 9)
+        for (const char* c = argc > 4 ? argv[4] : "9"; *c;) { Bs.push_back(atoi(c)); while (*c && *c != ',') ++c; if (*c) ++c; }
         const int sp[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 24};
         for (const S2& q : ss) for (int B : Bs) {
             const size_t nx = (size_t)B * q.R * q.R * q.Ci, no = (size_t)B * q.R * q.R * q.Co, nraw = (size_t)q.Co * q.Ci * q.K * q.K;
