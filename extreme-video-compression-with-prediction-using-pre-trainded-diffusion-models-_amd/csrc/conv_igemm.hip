@@ -44,15 +44,14 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #ifndef EVC_SPLIT_WIDE_TILES
 #define EVC_SPLIT_WIDE_TILES 1 // 256-pixel / 8-wave form of the row-reuse kernel on grids of whole rounds (run-time option "wide_tiles")
 #endif
-#ifndef EVC_RR_PRIO
-#define EVC_RR_PRIO 0
-#endif
+
 #ifndef EVC_SPLIT_INTERLEAVE
 #define EVC_SPLIT_INTERLEAVE 5 // bf16x6 pipelined kernel: VALU instructions scheduled per MFMA in the second half (0 = compiler's order)
 #endif
 // Variants that were measured and did not pay -- 2-D patch tiles, a software-pipelined row-reuse loop, staging balance /
 // interleave switches, XCD-contiguous tile order, LDS-DMA of plain activation tiles, producer / consumer specialised kernels,
-// an in-kernel ("last-arriver") split-K combine, weight DMA issued mid-step, the ablation diagnostics behind profiles/r02_conv_bench_ablation*.log --
+// an in-kernel ("last-arriver") split-K combine, weight DMA issued mid-step, a ping-pong schedule of the 8-wave tile, a static
+// priority for one of the two workgroups of a CU, the ablation diagnostics behind profiles/r02_conv_bench_ablation*.log --
 // live in tools/experiments/, outside this file.
 
 namespace {
@@ -928,16 +927,6 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kerne
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
-#if EVC_RR_PRIO
-    // EXPERIMENT: the two workgroups that share a CU get different static priorities (by the hardware wave slot their waves
-    // occupy on the SIMD), so that contention for the matrix pipe / issue slots is always resolved the same way and the
-    // favoured workgroup runs at its lone speed while the other fills the gaps -- instead of both running in lockstep.
-    {
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        if (hwid & 1u) __builtin_amdgcn_s_setprio(EVC_RR_PRIO);
-    }
-#endif
 
     // K-split tail (ConvK::tail_*): blockIdx.x beyond the unsplit tiles enumerates (tile, split) pairs of the last tiles
     const bool tail = WM == 2 && (int)blockIdx.x >= p.tail_first;
