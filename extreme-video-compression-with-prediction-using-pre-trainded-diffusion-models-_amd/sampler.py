@@ -82,18 +82,43 @@ def ddpm_sampler(*args, **kwargs):
 def ddpm_steps(x_mod, scorenet, cond=None, just_beta=False, final_only=False, denoise=True,
                subsample_steps=None, same_noise=False, noise_val=None, frac_steps=None, verbose=False,
                log=False, clip_before=True, t_min=-1, gamma=False, noise_fn=None, generator=None, **kwargs):
-    """Generator form of ``ddpm_sampler``: yields after every network evaluation + update."""
-    if gamma or frac_steps is not None or t_min > 0:
-        raise NotImplementedError("gamma / frac_steps / t_min>0 are unreachable from the reference CLI")
+    """Generator form of ``ddpm_sampler``: yields after every network evaluation + update.
+
+    ``frac_steps``: only the last fraction of the steps (models/__init__.py:248-256).  ``t_min`` > 0: ``x_mod`` is a clean
+    previous frame; steps with label < t_min * (number of steps) are skipped and the first executed step first noises the
+    input to its level, x <- sqrt(a_i) x + sqrt(1 - a_i) z (:266-277; z = ``noise_fn("t_min", x)`` when noise is injected).
+    ``gamma`` (Gamma-distributed noise) needs the model's k_cum / theta_t buffers, which mine.yml (gamma: false) never
+    builds: NotImplementedError."""
+    if gamma:
+        raise NotImplementedError("gamma noise needs net.k_cum / net.theta_t (config.model.gamma: false in configs/mine.yml)")
     net = _net(scorenet)
     steps, alphas, alphas_prev, betas = _subsample(net, subsample_steps)
+    if frac_steps is not None:
+        # the reference indexes the (possibly subsampled) tables with the step LABELS (:250-253): only consistent without
+        # subsampling, where label == index; with it the reference raises IndexError, and so does this
+        steps = steps[int((1 - frac_steps) * len(steps)):]
+        idx = torch.as_tensor([int(v) for v in steps], dtype=torch.long)
+        if len(idx) and int(idx.max()) >= len(alphas):
+            raise IndexError("frac_steps with subsample_steps indexes the subsampled schedule by label (reference behaviour)")
+        alphas, alphas_prev, betas = alphas[idx], alphas_prev[idx], betas[idx]
     L_ = len(steps)
-    _prepare(net, [int(s) for s in steps] + ([L_ - 1] if denoise else []))
+    run = [i for i, st in enumerate(steps) if not (int(st) < t_min * len(alphas))]
+    _prepare(net, [int(steps[i]) for i in run] + ([L_ - 1] if denoise else []))
     x = x_mod.detach().to(torch.float32).clone().contiguous()
     if same_noise and noise_val is None:
         noise_val = x.clone()
     images = []
-    for i, step in enumerate(steps):
+    x_transf = False
+
+    def draw(tag):
+        if noise_fn is not None:
+            return noise_fn(tag, x).to(x.device, torch.float32).contiguous()
+        return torch.randn(x.shape, device=x.device, dtype=torch.float32, generator=generator)
+    for i in run:
+        step = steps[i]
+        if not x_transf and t_min > 0:          # noise the clean input to this step's level
+            x = L.lincomb4([x, draw("t_min")], [float(alphas[i].sqrt()), float((1 - alphas[i]).sqrt())])
+        x_transf = True
         c_beta, c_alpha, c_alpha_prev = betas[i], alphas[i], alphas_prev[i]
         e = _eps(net, x, int(step), cond)
         k1 = float(1 / c_alpha.sqrt())
@@ -102,12 +127,7 @@ def ddpm_steps(x_mod, scorenet, cond=None, just_beta=False, final_only=False, de
         c2 = float((1 - c_beta).sqrt() * (1 - c_alpha_prev) / (1 - c_alpha))
         noise, sigma = None, 0.0
         if i + 1 != L_:
-            if same_noise:
-                noise = noise_val
-            elif noise_fn is not None:
-                noise = noise_fn(i, x).to(x.device, torch.float32).contiguous()
-            else:
-                noise = torch.randn(x.shape, device=x.device, dtype=torch.float32, generator=generator)
+            noise = noise_val if same_noise else draw(i)
             sigma = float(c_beta.sqrt()) if just_beta else float(((1 - c_alpha_prev) / (1 - c_alpha) * c_beta).sqrt())
         L.ddpm_step(x, e, noise, k1, k2, c1, c2, sigma, clip_before)
         if not final_only:
@@ -129,16 +149,25 @@ def ddim_sampler(*args, **kwargs):
 
 def ddim_steps(x_mod, scorenet, cond=None, final_only=False, denoise=True, subsample_steps=None, verbose=False,
                log=True, clip_before=True, t_min=-1, gamma=False, **kwargs):
-    """Generator form of ``ddim_sampler``."""
-    if gamma or t_min > 0:
-        raise NotImplementedError("gamma / t_min>0 are unreachable from the reference CLI")
+    """Generator form of ``ddim_sampler``; ``t_min`` as in ``ddpm_steps`` (models/__init__.py:145-157)."""
+    if gamma:
+        raise NotImplementedError("gamma noise needs net.k_cum / net.theta_t (config.model.gamma: false in configs/mine.yml)")
+    noise_fn, generator = kwargs.get("noise_fn"), kwargs.get("generator")
     net = _net(scorenet)
     steps, alphas, alphas_prev, betas = _subsample(net, subsample_steps)
     L_ = len(steps)
-    _prepare(net, [int(s) for s in steps] + ([L_ - 1] if denoise else []))
+    run = [i for i, st in enumerate(steps) if not (int(st) < t_min * len(alphas))]
+    _prepare(net, [int(steps[i]) for i in run] + ([L_ - 1] if denoise else []))
     x = x_mod.detach().to(torch.float32).clone().contiguous()
     images = []
-    for i, step in enumerate(steps):
+    x_transf = False
+    for i in run:
+        step = steps[i]
+        if not x_transf and t_min > 0:
+            z = noise_fn("t_min", x).to(x.device, torch.float32).contiguous() if noise_fn is not None else \
+                torch.randn(x.shape, device=x.device, dtype=torch.float32, generator=generator)
+            x = L.lincomb4([x, z], [float(alphas[i].sqrt()), float((1 - alphas[i]).sqrt())])
+        x_transf = True
         c_alpha, c_alpha_prev = alphas[i], alphas_prev[i]
         e = _eps(net, x, int(step), cond)
         L.ddim_step(x, e, float(1 / c_alpha.sqrt()), float((1 - c_alpha).sqrt()), float(c_alpha_prev.sqrt()),

@@ -1,8 +1,8 @@
 """Oracle: DDPM / DDIM / F-PNDM sampling loops (test infrastructure only).
 
 Restates reference ``models/__init__.py:207-342`` (ddpm_sampler), ``:103-204`` (ddim_sampler),
-``:39-100`` (FPNDM_sampler) and ``models/pndm.py:3-52`` for the settings the CLI can reach
-(``t_min=-1``, ``gamma=False``, ``just_beta=False``, ``frac_steps=None``, ``final_only=True``).
+``:39-100`` (FPNDM_sampler) and ``models/pndm.py:3-52`` for ``gamma=False``, ``just_beta=False``, ``final_only=True``
+(the CLI's settings), plus the ``t_min`` / ``frac_steps`` options of the DDPM / DDIM loops.
 
 ``eps_fn(x, labels)`` is the score network with ``cond`` already bound; ``labels`` is an int64
 (DDPM/DDIM) or float (F-PNDM) tensor of shape (B,).  ``noise_fn(i, x)`` supplies the Gaussian noise
@@ -19,11 +19,22 @@ def _labels(value, x, long=True):
 
 
 @torch.no_grad()
-def ddpm(x, eps_fn, sched, subsample_steps=None, denoise=True, clip_before=True, noise_fn=None):
+def ddpm(x, eps_fn, sched, subsample_steps=None, denoise=True, clip_before=True, noise_fn=None, t_min=-1, frac_steps=None):
     betas, alphas, alphas_prev = sched
     steps, alphas, alphas_prev, betas = subsample(alphas, alphas_prev, betas, subsample_steps)
+    if frac_steps is not None:                                                        # :248-253 (tables indexed by LABEL)
+        steps = steps[int((1 - frac_steps) * len(steps)):]
+        idx = torch.as_tensor([int(v) for v in steps], dtype=torch.long)
+        alphas, alphas_prev, betas = alphas[idx], alphas_prev[idx], betas[idx]
     L = len(steps)
+    x_transf = False
     for i, step in enumerate(steps):
+        if step < t_min * len(alphas):                                                # :263-264
+            continue
+        if not x_transf and t_min > 0:                                                # :266-276
+            z = noise_fn("t_min", x) if noise_fn is not None else torch.randn_like(x)
+            x = alphas[i].sqrt() * x + (1 - alphas[i]).sqrt() * z
+        x_transf = True
         c_beta, c_alpha, c_alpha_prev = betas[i], alphas[i], alphas_prev[i]
         grad = eps_fn(x, _labels(step, x))                                            # :285-286
         x0 = (1 / c_alpha.sqrt()) * (x - (1 - c_alpha).sqrt() * grad)                 # :289
@@ -41,11 +52,18 @@ def ddpm(x, eps_fn, sched, subsample_steps=None, denoise=True, clip_before=True,
 
 
 @torch.no_grad()
-def ddim(x, eps_fn, sched, subsample_steps=None, denoise=True, clip_before=True):
+def ddim(x, eps_fn, sched, subsample_steps=None, denoise=True, clip_before=True, t_min=-1, noise_fn=None):
     betas, alphas, alphas_prev = sched
     steps, alphas, alphas_prev, betas = subsample(alphas, alphas_prev, betas, subsample_steps)
     L = len(steps)
+    x_transf = False
     for i, step in enumerate(steps):
+        if step < t_min * len(alphas):                                                # :145-146
+            continue
+        if not x_transf and t_min > 0:                                                # :148-156
+            z = noise_fn("t_min", x) if noise_fn is not None else torch.randn_like(x)
+            x = alphas[i].sqrt() * x + (1 - alphas[i]).sqrt() * z
+        x_transf = True
         c_alpha, c_alpha_prev = alphas[i], alphas_prev[i]
         grad = eps_fn(x, _labels(step, x))
         x0 = (1 / c_alpha.sqrt()) * (x - (1 - c_alpha).sqrt() * grad)                 # :163

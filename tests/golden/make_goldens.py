@@ -174,6 +174,29 @@ def gen_samplers():
     save("label_sequences", **out)
 
 
+def gen_sampler_options():
+    """The DDPM / DDIM options the shipped CLI never sets: ``t_min`` > 0 (start from a clean frame, skip the early steps,
+    noise the input to the first executed level; models/__init__.py:263-277, :145-157) and ``frac_steps`` (only the last
+    fraction of the un-subsampled schedule; :248-256).  Reduced net, injected noise."""
+    from models import ddpm_sampler, ddim_sampler
+    net, d = ref_net(32, 32, 32, 41)
+    x0, cond = rnd(46, 2, 15, 32, 32).clamp(-1, 1), rnd(43, 2, 6, 32, 32)
+    out = {}
+    orig = torch.randn_like
+    for name, fn, kw, n_noise in (("ddpm_tmin", ddpm_sampler, dict(subsample_steps=10, t_min=0.35), 12),
+                                  ("ddim_tmin", ddim_sampler, dict(subsample_steps=10, t_min=0.35), 1),
+                                  ("ddpm_frac", ddpm_sampler, dict(frac_steps=0.006), 8)):
+        noises = [rnd(300 + i, 2, 15, 32, 32) for i in range(n_noise)]
+        it = iter(noises)
+        torch.randn_like = lambda t, **k: next(it)
+        try:
+            out[name] = fn(x0.clone(), net, cond=cond, denoise=True, clip_before=True, final_only=True, log=False, **kw)
+        finally:
+            torch.randn_like = orig
+        out[name + "_noises_used"] = np.asarray(n_noise - len(list(it)))
+    save("sampler_options", **out)
+
+
 def gen_forward_full():
     torch.set_num_threads(8)
     net, d = ref_net(192, 192, 128, 1234)
@@ -307,7 +330,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     gens = dict(schedule=gen_schedule, fir=gen_fir, blocks=gen_blocks, forward_reduced=gen_forward_reduced,
-                samplers=gen_samplers, forward_full=gen_forward_full, forward_full_b9=gen_forward_full_b9,
+                samplers=gen_samplers, sampler_options=gen_sampler_options, forward_full=gen_forward_full, forward_full_b9=gen_forward_full_b9,
                 traj_full=gen_traj_full, traj_fpndm_full=gen_traj_fpndm_full, unet_ddpm=gen_unet_ddpm, forward_spade=gen_forward_spade)
     for name, fn in gens.items():
         if a.only and name != a.only:

@@ -249,6 +249,33 @@ def test_sampler_trajectories_against_reference_goldens():
     assert rel(out, g["fpndm"]) < 5e-4
 
 
+def test_sampler_options_t_min_and_frac_steps_against_reference_goldens():
+    """``t_min`` > 0 (start from a clean frame: skip the early steps, noise the input to the first executed level) and
+    ``frac_steps`` (only the last fraction of the un-subsampled schedule) of the DDPM / DDIM loops -- options no shipped
+    config sets (models/__init__.py:248-277, :145-157) -- against the reference run with the same injected noise;
+    ``gamma`` stays NotImplementedError (needs model buffers mine.yml never builds)."""
+    import evc_amd  # noqa: F401
+    from evc_amd import sampler
+    g = golden("sampler_options")
+    net, d, p = build(32, 32, 32, 41)
+    x0, cond = rnd(46, 2, 15, 32, 32).clamp(-1, 1).cuda(), rnd(43, 2, 6, 32, 32).cuda()
+
+    def feed(n):
+        it = iter([rnd(300 + i, 2, 15, 32, 32) for i in range(n)])
+        return lambda tag, x: next(it)
+    kw = dict(cond=cond, denoise=True, clip_before=True, final_only=True)
+    out = sampler.ddpm_sampler(x0, net, subsample_steps=10, t_min=0.35, noise_fn=feed(int(g["ddpm_tmin_noises_used"])), **kw)
+    assert out.shape == g["ddpm_tmin"].shape and rel(out, g["ddpm_tmin"]) < 5e-4
+    out = sampler.ddim_sampler(x0, net, subsample_steps=10, t_min=0.35, noise_fn=feed(int(g["ddim_tmin_noises_used"])), **kw)
+    assert rel(out, g["ddim_tmin"]) < 5e-4
+    out = sampler.ddpm_sampler(x0, net, frac_steps=0.006, noise_fn=feed(int(g["ddpm_frac_noises_used"])), **kw)
+    assert rel(out, g["ddpm_frac"]) < 5e-4
+    with pytest.raises(NotImplementedError):
+        sampler.ddpm_sampler(x0, net, subsample_steps=10, gamma=True, **kw)
+    with pytest.raises(IndexError):           # the reference indexes the subsampled tables by label here, and fails the same way
+        sampler.ddpm_sampler(x0, net, subsample_steps=10, frac_steps=0.5, **kw)
+
+
 def test_sampler_label_sequences_match_reference():
     import evc_amd  # noqa: F401
     from evc_amd import sampler

@@ -96,6 +96,26 @@ def test_sampler_trajectories():
     assert _rel(out.numpy(), g["fpndm"]) < 1e-4
 
 
+def test_sampler_options_t_min_and_frac_steps():
+    """The DDPM / DDIM options no shipped config sets, against the reference run with injected noise
+    (models/__init__.py:248-277, :145-157): t_min > 0 and frac_steps."""
+    g = golden("sampler_options")
+    d, p = _net(41)
+    x0, cond = rnd(46, 2, 15, 32, 32).clamp(-1, 1), rnd(43, 2, 6, 32, 32)
+    eps = lambda x, t: scorenet.forward(p, d, x, t, cond=cond)
+    sched = schedule.base_schedule()
+
+    def feed(n):
+        it = iter([rnd(300 + i, 2, 15, 32, 32) for i in range(n)])
+        return lambda tag, x: next(it)
+    out = samplers.ddpm(x0.clone(), eps, sched, subsample_steps=10, t_min=0.35, noise_fn=feed(int(g["ddpm_tmin_noises_used"])))
+    assert _rel(out.numpy(), g["ddpm_tmin"]) < 1e-4
+    out = samplers.ddim(x0.clone(), eps, sched, subsample_steps=10, t_min=0.35, noise_fn=feed(int(g["ddim_tmin_noises_used"])))
+    assert _rel(out.numpy(), g["ddim_tmin"]) < 1e-4
+    out = samplers.ddpm(x0.clone(), eps, sched, frac_steps=0.006, noise_fn=feed(int(g["ddpm_frac_noises_used"])))
+    assert _rel(out.numpy(), g["ddpm_frac"]) < 1e-4
+
+
 def test_label_sequences():
     g = golden("label_sequences")
     sched = schedule.base_schedule()
