@@ -14,7 +14,7 @@ for set in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" \
            "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
   echo "pass $i: $set"
-  timeout -k 5 120 rocprofv3 --kernel-trace --pmc $set -d "$OUT/p$i" -o pass --output-format csv -- ./tools/conv_bench_split ${LAYOUT:-5} 3 "$SHAPE" > "$OUT/p$i.log" 2>&1 || echo "pass $i failed"
+  timeout -k 5 120 rocprofv3 --kernel-trace --pmc $set -d "$OUT/p$i" -o pass --output-format csv -- ${BENCH:-./tools/conv_bench_r03} ${LAYOUT:-6} 3 "$SHAPE" > "$OUT/p$i.log" 2>&1 || echo "pass $i failed"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
