@@ -114,10 +114,16 @@ def roofline_leg(net, clips, device):
     prof = []
     L.CONV_PROFILE = prof
     reps = 3
+    tf0 = time.perf_counter()
+    net.forward_label(x, 500, c)
+    torch.cuda.synchronize()
+    probe = L.ClockProbe(int(max(1.0, 0.8 * reps * (time.perf_counter() - tf0) * 1e3) * 1e3), device)   # spans ~80 % of the forwards below
+    prof.clear()
     for _ in range(reps):
         net.forward_label(x, 500, c)
     L.CONV_PROFILE = None
     torch.cuda.synchronize()
+    live_clock = probe.ghz()
     net.overlap_skip, net.use_graphs = overlap, graphs
     per, kern = {}, {}
     mode_of = lambda c: (2 if c["act_in"] == L.ACT_SILU else 1) if c["coef"] else {L.ACT_SILU: 3, L.ACT_RELU: 4}.get(c["act_in"], 0)
@@ -170,8 +176,7 @@ def roofline_leg(net, clips, device):
                                       "calls": int(row["Calls"]), "frac": round(gflop * 1e9 / (rus * 1e-6) / 1e12 / peak, 4)}
                     break
             if meta.get("held_clock_ghz"):
-                out["held_clock_ghz"] = meta["held_clock_ghz"]
-                out["frac_at_held_clock"] = round(achieved / (peak * meta["held_clock_ghz"] / 2.4), 4)
+                out.setdefault("rocprof", {})["held_clock_ghz_pmc"] = meta["held_clock_ghz"]
             if meta.get("mfma_busy_frac"):
                 out["mfma_busy_frac_pmc"] = meta["mfma_busy_frac"]
         else:
@@ -179,6 +184,13 @@ def roofline_leg(net, clips, device):
                               f"B={meta.get('batch')}, this is {source_sha()} at B={clips}: not quoted")
     except Exception:
         pass
+    if live_clock:
+        # the chip does not hold its 2.4 GHz peak under these kernels: the package sits at its 1 400 W power cap (profiles/NOTES.md,
+        # r03_power_cap.log) and the shader clock settles where the cap puts it; `peak` is priced at 2.4 GHz regardless
+        out["held_clock_ghz"] = round(live_clock, 3)
+        out["held_clock_note"] = ("s_memtime / s_memrealtime of an idle probe wave (evc_clock_probe) across these forwards; "
+                                  "2.4 GHz is the clock `peak` assumes")
+        out["frac_at_held_clock"] = round(achieved / (peak * live_clock / 2.4), 4)
     prov = "no rocprofv3 PMC profile committed for this kernel source"
     try:       # HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, only if taken on THIS source
         pmc = json.load(open(os.path.join(REPO, "profiles", f"r03_conv_{aname}_pmc.json")))
@@ -419,18 +431,26 @@ def main():
     def step():
         return dec.decode(d, key_strings, shape, generator=gen)
 
+    t_warm = None
     for i in range(a.warmup):
+        tw = time.perf_counter()
         step()
         torch.cuda.synchronize()
+        t_warm = time.perf_counter() - tw
         if rank == 0:
             progress(f"warm-up step {i + 1}/{a.warmup} done")
     D.barrier()
     torch.cuda.synchronize()
+    # shader clock the chip holds during the timed region (it runs into the package power cap under the convolutions): an
+    # idle one-wave probe on its own stream, sized from the warm-up step so that it ends well inside the region
+    probe = L.ClockProbe(int(min(2.0, 0.5 * t_warm * a.steps) * 1e6), device) if (rank == 0 and t_warm) else None
     t0 = time.perf_counter()
     for _ in range(a.steps):
         frames = step()
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0            # this rank's own time, before it waits for the others
+    power_w = L.gpu_power_w(device) if rank == 0 else None     # the driver's ~1 s average at the end of the last step
+    clock_ghz = probe.ghz() if probe is not None else None
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
     per_rank = [round(a.clips * 30 * a.steps / t, 3) for t in D.gather_over_ranks(own_elapsed, device)]
@@ -470,6 +490,8 @@ def main():
                                      f"group(s) per GPU; forwards {'replayed from HIP graphs' if a.graphs else 'launched eagerly'}",
                       "weights": "seeded random, reference architecture (262.1M + ELIC)"},
            "per_rank_value": per_rank, "range_events": events,
+           "timed_region_shader_clock_ghz": None if clock_ghz is None else round(clock_ghz, 3),
+           "timed_region_end_package_power_w": None if power_w is None else round(power_w),
            "whole_path_tflops_per_gpu": round(flop_per_step_gpu * a.steps / elapsed / 1e12, 2),
            "elic_keyframe_decode_ms_per_step": round(elic_ms, 1)}
     if rank == 0:

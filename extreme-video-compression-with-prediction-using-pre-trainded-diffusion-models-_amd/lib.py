@@ -76,6 +76,7 @@ HIP_SYMBOLS = {
     "evc_version": (c_char_p, []),
     "evc_arch": (c_char_p, []),
     "evc_device_ok": (c_int, []),
+    "evc_clock_probe": (c_int, [c_void_p, c_int, c_void_p]),
     "evc_upfirdn2d_f32": (c_int, [c_void_p, c_void_p, POINTER(c_float)] + [c_int] * 13 + [c_void_p]),
     "evc_upfirdn2d_nhwc_f32": (c_int, [c_void_p, c_void_p, POINTER(c_float)] + [c_int] * 10 +
                                [c_void_p, c_void_p, c_int, c_void_p]),
@@ -318,6 +319,38 @@ def range_events(device=None, reset=False):
     if reset:
         w.zero_()
     return v
+
+
+class ClockProbe:
+    """Shader clock held by the chip over the next ``spin_us`` microseconds, measured by a one-wave idle kernel on its own
+    stream (``evc_clock_probe``): start it, run the work to be characterised on other streams, then read ``ghz()``."""
+
+    def __init__(self, spin_us, device=None):
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.out = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        _check(hip_lib().evc_clock_probe(self.out.data_ptr(), int(spin_us), self.stream.cuda_stream), "evc_clock_probe")
+
+    def ghz(self):
+        self.stream.synchronize()
+        ticks, ref = (int(v) for v in self.out.tolist())
+        return ticks / ref * 0.1 if ref else None
+
+
+def gpu_power_w(device=None):
+    """Average package power (W) of ``device`` from sysfs (hwmon power1_average of the card with the device's PCI address), or
+    None where that is not readable.  Read-only; the figure is the driver's ~1 s moving average."""
+    import glob as _glob
+    try:
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device() if device is None else torch.device(device).index)
+        addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+        for card in _glob.glob("/sys/class/drm/card*/device"):
+            if addr in os.path.realpath(card):
+                for f in _glob.glob(card + "/hwmon/hwmon*/power1_average") + _glob.glob(card + "/hwmon/hwmon*/power1_input"):
+                    return int(open(f).read()) / 1e6
+    except Exception:
+        return None
+    return None
 
 
 def gn_coeffs(parts, HW, groups, eps, mode=0, gamma=None, beta=None, ss=None, row=None, bound=None):

@@ -42,6 +42,32 @@ def _subsample(net, subsample_steps):
     return steps, alphas, alphas_prev, betas
 
 
+def _gamma_tables(net, steps, full_len):
+    """ks_cum / thetas of the ``gamma=True`` branch (models/__init__.py:226-227, 241-243): the model's Gamma-noise buffers,
+    subsampled like the alphas.  A model built without ``config.model.gamma`` has none."""
+    if not hasattr(net, "k_cum"):
+        raise NotImplementedError("gamma=True needs the model's k_cum / theta_t buffers: build it with config.model.gamma = true "
+                                  "(configs/mine.yml has gamma: false)")
+    ks, th = net.k_cum.cpu(), net.theta_t.cpu()
+    if len(steps) < full_len:
+        ks, th = ks.index_select(0, steps), th.index_select(0, steps)
+    return ks, th
+
+
+def _gamma_noise(x, k, theta, alpha, raw=None, generator=None):
+    """One Gamma-distributed noise tensor, standardised as the reference does (models/__init__.py:322-324):
+    z ~ Gamma(k, rate 1/theta) per element, noise = (z - k theta) / sqrt(1 - alpha).  ``raw``: an injected z."""
+    if raw is None:
+        conc = torch.full(tuple(x.shape), float(k), device=x.device)
+        # what torch.distributions.Gamma(conc, rate).sample() does (standard gamma / rate), with the caller's generator
+        raw = torch._standard_gamma(conc, generator=generator) / float(1.0 / theta)
+    raw = raw.to(x.device, torch.float32).contiguous()
+    # z - k theta first, in fp32 like the reference: both are ~1e3 with a difference of order 1, so folding the subtraction
+    # into one multiply-add with pre-divided constants would cost ~1e-4 of the noise
+    centred = L.scale_clamp(raw, 1.0, -float(k * theta))
+    return L.scale_clamp(centred, float(1.0 / (1 - alpha).sqrt()), 0.0, out=centred)
+
+
 def _prepare(net, labels):
     if hasattr(net, "prepare_labels"):
         net.prepare_labels(labels)
@@ -87,12 +113,13 @@ def ddpm_steps(x_mod, scorenet, cond=None, just_beta=False, final_only=False, de
     ``frac_steps``: only the last fraction of the steps (models/__init__.py:248-256).  ``t_min`` > 0: ``x_mod`` is a clean
     previous frame; steps with label < t_min * (number of steps) are skipped and the first executed step first noises the
     input to its level, x <- sqrt(a_i) x + sqrt(1 - a_i) z (:266-277; z = ``noise_fn("t_min", x)`` when noise is injected).
-    ``gamma`` (Gamma-distributed noise) needs the model's k_cum / theta_t buffers, which mine.yml (gamma: false) never
-    builds: NotImplementedError."""
-    if gamma:
-        raise NotImplementedError("gamma noise needs net.k_cum / net.theta_t (config.model.gamma: false in configs/mine.yml)")
+    ``gamma``: the noise is a standardised Gamma sample of the model's k_cum / theta_t buffers (:226-227, :322-324; built only
+    when config.model.gamma is set -- mine.yml has gamma: false -- otherwise NotImplementedError)."""
     net = _net(scorenet)
     steps, alphas, alphas_prev, betas = _subsample(net, subsample_steps)
+    ks_cum = thetas = None
+    if gamma:
+        ks_cum, thetas = _gamma_tables(net, steps, len(net.betas))
     if frac_steps is not None:
         # the reference indexes the (possibly subsampled) tables with the step LABELS (:250-253): only consistent without
         # subsampling, where label == index; with it the reference raises IndexError, and so does this
@@ -101,6 +128,8 @@ def ddpm_steps(x_mod, scorenet, cond=None, just_beta=False, final_only=False, de
         if len(idx) and int(idx.max()) >= len(alphas):
             raise IndexError("frac_steps with subsample_steps indexes the subsampled schedule by label (reference behaviour)")
         alphas, alphas_prev, betas = alphas[idx], alphas_prev[idx], betas[idx]
+        if gamma:
+            ks_cum, thetas = ks_cum[idx], thetas[idx]
     L_ = len(steps)
     run = [i for i, st in enumerate(steps) if not (int(st) < t_min * len(alphas))]
     _prepare(net, [int(steps[i]) for i in run] + ([L_ - 1] if denoise else []))
@@ -110,14 +139,19 @@ def ddpm_steps(x_mod, scorenet, cond=None, just_beta=False, final_only=False, de
     images = []
     x_transf = False
 
-    def draw(tag):
-        if noise_fn is not None:
-            return noise_fn(tag, x).to(x.device, torch.float32).contiguous()
+    def draw(tag, i):
+        """The noise the reference draws at this point: Gaussian, or (gamma) a standardised Gamma sample of step i's
+        parameters; an injected ``noise_fn`` supplies the RAW draw (randn / Gamma sample) in both cases."""
+        raw = None if noise_fn is None else noise_fn(tag, x)
+        if gamma:
+            return _gamma_noise(x, ks_cum[i], thetas[i], alphas[i], raw=raw, generator=generator)
+        if raw is not None:
+            return raw.to(x.device, torch.float32).contiguous()
         return torch.randn(x.shape, device=x.device, dtype=torch.float32, generator=generator)
     for i in run:
         step = steps[i]
         if not x_transf and t_min > 0:          # noise the clean input to this step's level
-            x = L.lincomb4([x, draw("t_min")], [float(alphas[i].sqrt()), float((1 - alphas[i]).sqrt())])
+            x = L.lincomb4([x, draw("t_min", i)], [float(alphas[i].sqrt()), float((1 - alphas[i]).sqrt())])
         x_transf = True
         c_beta, c_alpha, c_alpha_prev = betas[i], alphas[i], alphas_prev[i]
         e = _eps(net, x, int(step), cond)
@@ -127,7 +161,7 @@ def ddpm_steps(x_mod, scorenet, cond=None, just_beta=False, final_only=False, de
         c2 = float((1 - c_beta).sqrt() * (1 - c_alpha_prev) / (1 - c_alpha))
         noise, sigma = None, 0.0
         if i + 1 != L_:
-            noise = noise_val if same_noise else draw(i)
+            noise = noise_val if same_noise else draw(i, i)
             sigma = float(c_beta.sqrt()) if just_beta else float(((1 - c_alpha_prev) / (1 - c_alpha) * c_beta).sqrt())
         L.ddpm_step(x, e, noise, k1, k2, c1, c2, sigma, clip_before)
         if not final_only:
@@ -149,12 +183,14 @@ def ddim_sampler(*args, **kwargs):
 
 def ddim_steps(x_mod, scorenet, cond=None, final_only=False, denoise=True, subsample_steps=None, verbose=False,
                log=True, clip_before=True, t_min=-1, gamma=False, **kwargs):
-    """Generator form of ``ddim_sampler``; ``t_min`` as in ``ddpm_steps`` (models/__init__.py:145-157)."""
-    if gamma:
-        raise NotImplementedError("gamma noise needs net.k_cum / net.theta_t (config.model.gamma: false in configs/mine.yml)")
+    """Generator form of ``ddim_sampler``; ``t_min`` / ``gamma`` as in ``ddpm_steps`` (models/__init__.py:145-157; DDIM draws
+    noise only for the t_min start)."""
     noise_fn, generator = kwargs.get("noise_fn"), kwargs.get("generator")
     net = _net(scorenet)
     steps, alphas, alphas_prev, betas = _subsample(net, subsample_steps)
+    ks_cum = thetas = None
+    if gamma:
+        ks_cum, thetas = _gamma_tables(net, steps, len(net.betas))
     L_ = len(steps)
     run = [i for i, st in enumerate(steps) if not (int(st) < t_min * len(alphas))]
     _prepare(net, [int(steps[i]) for i in run] + ([L_ - 1] if denoise else []))
@@ -164,8 +200,13 @@ def ddim_steps(x_mod, scorenet, cond=None, final_only=False, denoise=True, subsa
     for i in run:
         step = steps[i]
         if not x_transf and t_min > 0:
-            z = noise_fn("t_min", x).to(x.device, torch.float32).contiguous() if noise_fn is not None else \
-                torch.randn(x.shape, device=x.device, dtype=torch.float32, generator=generator)
+            raw = None if noise_fn is None else noise_fn("t_min", x)
+            if gamma:
+                z = _gamma_noise(x, ks_cum[i], thetas[i], alphas[i], raw=raw, generator=generator)
+            elif raw is not None:
+                z = raw.to(x.device, torch.float32).contiguous()
+            else:
+                z = torch.randn(x.shape, device=x.device, dtype=torch.float32, generator=generator)
             x = L.lincomb4([x, z], [float(alphas[i].sqrt()), float((1 - alphas[i]).sqrt())])
         x_transf = True
         c_alpha, c_alpha_prev = alphas[i], alphas_prev[i]

@@ -132,6 +132,12 @@ class ScoreNet:
         self.betas = torch.linspace(self.d.sigma_begin, self.d.sigma_end, self.d.num_classes)
         self.alphas = torch.cumprod(1 - self.betas.flip(0), 0).flip(0)
         self.alphas_prev = torch.cat([self.alphas[1:], torch.tensor([1.0]).to(self.alphas)])
+        self.gamma = bool(getattr(m, "gamma", False))
+        if self.gamma:       # Gamma-noise schedule buffers, ncsnpp_more.py:744-749 (read by the samplers' gamma=True branch)
+            self.theta_0 = 0.001
+            self.k = self.betas / (self.alphas * (self.theta_0 ** 2))
+            self.k_cum = torch.cumsum(self.k.flip(0), 0).flip(0)
+            self.theta_t = torch.sqrt(self.alphas) * self.theta_0
         self.program = build_program(self.d)
         if self.SPADE:     # the conditioning frames do not enter through the input (ncsnpp_more.py:519, :593-594)
             self.program[2]["cin"] = self.d.channels * self.d.num_frames

@@ -2,15 +2,39 @@
 
 Restates reference ``models/__init__.py:207-342`` (ddpm_sampler), ``:103-204`` (ddim_sampler),
 ``:39-100`` (FPNDM_sampler) and ``models/pndm.py:3-52`` for ``gamma=False``, ``just_beta=False``, ``final_only=True``
-(the CLI's settings), plus the ``t_min`` / ``frac_steps`` options of the DDPM / DDIM loops.
+(the CLI's settings), plus the ``t_min`` / ``frac_steps`` / ``gamma`` options of the DDPM / DDIM loops.
 
 ``eps_fn(x, labels)`` is the score network with ``cond`` already bound; ``labels`` is an int64
 (DDPM/DDIM) or float (F-PNDM) tensor of shape (B,).  ``noise_fn(i, x)`` supplies the Gaussian noise
-added after step ``i`` (the reference draws ``torch.randn_like``; parity tests inject it).
+added after step ``i`` (the reference draws ``torch.randn_like``; parity tests inject it).  With ``gamma=(k_cum, theta_t)``
+(``schedule.gamma_schedule``) the draw is a Gamma(k_cum_i, rate 1/theta_i) sample instead -- ``noise_fn`` then supplies that
+RAW sample -- standardised as ``(z - k theta) / sqrt(1 - alpha)`` (models/__init__.py:150-153, :275-278, :321-324).
 """
 import torch
 
 from .schedule import base_schedule, subsample
+
+
+def _draw(tag, i, x, noise_fn, gamma_tabs, alphas):
+    if gamma_tabs is None:
+        return noise_fn(tag, x) if noise_fn is not None else torch.randn_like(x)
+    ks_cum, thetas = gamma_tabs
+    if noise_fn is not None:
+        z = noise_fn(tag, x)
+    else:
+        z = torch.distributions.gamma.Gamma(torch.full(x.shape[1:], ks_cum[i]),
+                                            torch.full(x.shape[1:], 1 / thetas[i])).sample((x.shape[0],)).to(x.device)
+    return (z - ks_cum[i] * thetas[i]) / ((1 - alphas[i]).sqrt())
+
+
+def _gamma_tabs(gamma, steps, full_len):
+    if gamma is None:
+        return None
+    ks_cum, thetas = gamma
+    if len(steps) < full_len:                                                         # :241-243
+        idx = torch.as_tensor([int(v) for v in steps], dtype=torch.long)
+        ks_cum, thetas = ks_cum.index_select(0, idx), thetas.index_select(0, idx)
+    return ks_cum, thetas
 
 
 def _labels(value, x, long=True):
@@ -19,20 +43,25 @@ def _labels(value, x, long=True):
 
 
 @torch.no_grad()
-def ddpm(x, eps_fn, sched, subsample_steps=None, denoise=True, clip_before=True, noise_fn=None, t_min=-1, frac_steps=None):
+def ddpm(x, eps_fn, sched, subsample_steps=None, denoise=True, clip_before=True, noise_fn=None, t_min=-1, frac_steps=None,
+         gamma=None):
     betas, alphas, alphas_prev = sched
+    full_len = len(betas)
     steps, alphas, alphas_prev, betas = subsample(alphas, alphas_prev, betas, subsample_steps)
-    if frac_steps is not None:                                                        # :248-253 (tables indexed by LABEL)
+    gamma = _gamma_tabs(gamma, steps, full_len)
+    if frac_steps is not None:                                                        # :248-258 (tables indexed by LABEL)
         steps = steps[int((1 - frac_steps) * len(steps)):]
         idx = torch.as_tensor([int(v) for v in steps], dtype=torch.long)
         alphas, alphas_prev, betas = alphas[idx], alphas_prev[idx], betas[idx]
+        if gamma is not None:
+            gamma = (gamma[0][idx], gamma[1][idx])
     L = len(steps)
     x_transf = False
     for i, step in enumerate(steps):
         if step < t_min * len(alphas):                                                # :263-264
             continue
         if not x_transf and t_min > 0:                                                # :266-276
-            z = noise_fn("t_min", x) if noise_fn is not None else torch.randn_like(x)
+            z = _draw("t_min", i, x, noise_fn, gamma, alphas)
             x = alphas[i].sqrt() * x + (1 - alphas[i]).sqrt() * z
         x_transf = True
         c_beta, c_alpha, c_alpha_prev = betas[i], alphas[i], alphas_prev[i]
@@ -44,7 +73,7 @@ def ddpm(x, eps_fn, sched, subsample_steps=None, denoise=True, clip_before=True,
             ((1 - c_beta).sqrt() * (1 - c_alpha_prev) / (1 - c_alpha)) * x            # :292
         if i + 1 == L:                                                                # :313-315
             continue
-        noise = noise_fn(i, x) if noise_fn is not None else torch.randn_like(x)
+        noise = _draw(i, i, x, noise_fn, gamma, alphas)                               # :321-326
         x = x + ((1 - c_alpha_prev) / (1 - c_alpha) * c_beta).sqrt() * noise          # :330
     if denoise:                                                                       # :333-335
         x = x - (1 - alphas[-1]).sqrt() * eps_fn(x, _labels(L - 1, x))
@@ -52,16 +81,18 @@ def ddpm(x, eps_fn, sched, subsample_steps=None, denoise=True, clip_before=True,
 
 
 @torch.no_grad()
-def ddim(x, eps_fn, sched, subsample_steps=None, denoise=True, clip_before=True, t_min=-1, noise_fn=None):
+def ddim(x, eps_fn, sched, subsample_steps=None, denoise=True, clip_before=True, t_min=-1, noise_fn=None, gamma=None):
     betas, alphas, alphas_prev = sched
+    full_len = len(betas)
     steps, alphas, alphas_prev, betas = subsample(alphas, alphas_prev, betas, subsample_steps)
+    gamma = _gamma_tabs(gamma, steps, full_len)
     L = len(steps)
     x_transf = False
     for i, step in enumerate(steps):
         if step < t_min * len(alphas):                                                # :145-146
             continue
         if not x_transf and t_min > 0:                                                # :148-156
-            z = noise_fn("t_min", x) if noise_fn is not None else torch.randn_like(x)
+            z = _draw("t_min", i, x, noise_fn, gamma, alphas)
             x = alphas[i].sqrt() * x + (1 - alphas[i]).sqrt() * z
         x_transf = True
         c_alpha, c_alpha_prev = alphas[i], alphas_prev[i]

@@ -26,3 +26,11 @@ def subsample(alphas, alphas_prev, betas, subsample_steps):
         alphas_prev = torch.cat([alphas[1:], torch.tensor([1.0]).to(alphas)])
         betas = 1.0 - torch.div(alphas, alphas_prev)
     return steps, alphas, alphas_prev, betas
+
+
+def gamma_schedule(betas, alphas, theta_0=0.001):
+    """ncsnpp_more.py:744-749: the (k, k_cum, theta_t) buffers a ``config.model.gamma`` model registers."""
+    k = betas / (alphas * (theta_0 ** 2))
+    k_cum = torch.cumsum(k.flip(0), 0).flip(0)
+    theta_t = torch.sqrt(alphas) * theta_0
+    return k, k_cum, theta_t

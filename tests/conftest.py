@@ -33,3 +33,28 @@ def golden(name):
 def rnd(seed, *shape):
     """Same seeded-input recipe as tests/golden/make_goldens.py."""
     return torch.from_numpy(np.random.default_rng(seed).standard_normal(shape, dtype=np.float32))
+
+
+def gamma_raw(count, k, theta, shape):
+    """Draw number ``count`` of tests/golden/make_goldens.py::gen_sampler_gamma (same recipe as its ``gamma_raw``): the
+    stand-in for a Gamma(k, rate 1/theta) sample, k theta + n / 2 with n = rnd(500 + count): IEEE fp32 mul / div / add only,
+    so it is the same tensor on every host."""
+    kk = torch.full(tuple(shape[1:]), float(k))
+    th = 1.0 / torch.full(tuple(shape[1:]), float(1 / theta))
+    return kk * th + 0.5 * rnd(500 + count, *shape)
+
+
+def gamma_feed(g, name, first, k_cum, theta_t, steps, shape=(2, 15, 32, 32)):
+    """noise_fn for a ``gamma=True`` run of golden ``name``: the generator's raw draws, numbered from ``first``, each
+    checked against the checksum the reference run recorded.  Returns (noise_fn, number of draws)."""
+    sums = g[name + "_raw_sums"]
+    state = {"n": 0}
+    ks, th = k_cum[steps], theta_t[steps]
+
+    def fn(tag, x):
+        i = tag if tag != "t_min" else state["first_step"]
+        raw = gamma_raw(first + state["n"], ks[i], th[i], shape)
+        assert float(raw.double().sum()) == float(sums[state["n"]]), (name, tag)
+        state["n"] += 1
+        return raw
+    return fn, state, len(sums)

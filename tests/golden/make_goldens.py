@@ -37,8 +37,9 @@ def d2n(d):
     return ns
 
 
-def ref_config(ngf, head, image_size):
+def ref_config(ngf, head, image_size, gamma=False):
     cfg = yaml.safe_load(open(os.path.join(REF, "configs/mine.yml")))
+    cfg["model"]["gamma"] = gamma
     cfg["model"]["ngf"] = ngf
     cfg["model"]["n_head_channels"] = head
     cfg["data"]["image_size"] = image_size
@@ -47,9 +48,9 @@ def ref_config(ngf, head, image_size):
     return config
 
 
-def ref_net(ngf, head, image_size, seed):
+def ref_net(ngf, head, image_size, seed, gamma=False):
     from models.better.ncsnpp_more import UNetMore_DDPM
-    net = UNetMore_DDPM(ref_config(ngf, head, image_size)).eval()
+    net = UNetMore_DDPM(ref_config(ngf, head, image_size, gamma)).eval()
     d = Dims(ngf=ngf, n_head_channels=head, image_size=image_size)
     p = seeded_params(d, seed)
     own = dict(net.named_parameters())
@@ -57,7 +58,8 @@ def ref_net(ngf, head, image_size, seed):
     for k, v in p.items():
         assert tuple(own[k].shape) == tuple(v.shape), k
     missing, unexpected = net.load_state_dict(p, strict=False)
-    assert not unexpected and all(m in ("betas", "alphas", "alphas_prev", "unet.sigmas") for m in missing), missing
+    assert not unexpected and all(m in ("betas", "alphas", "alphas_prev", "unet.sigmas", "k", "k_cum", "theta_t")
+                                  for m in missing), missing
     return net, d
 
 
@@ -197,6 +199,52 @@ def gen_sampler_options():
     save("sampler_options", **out)
 
 
+def gen_sampler_gamma():
+    """``gamma=True`` (models/__init__.py:119-153, :225-278, :321-324) on a ``config.model.gamma`` model: the schedule
+    buffers k / k_cum / theta_t (ncsnpp_more.py:744-749) and DDPM / DDIM runs whose Gamma draws are injected -- the
+    reference's ``Gamma(...).sample`` is replaced by a seeded positive tensor around the distribution's mean
+    (k theta + n / 2, n standard normal), recomputable by the tests so both sides consume the identical raw draw."""
+    import models as M
+    net, d = ref_net(32, 32, 32, 41, gamma=True)
+    x0, cond = rnd(46, 2, 15, 32, 32).clamp(-1, 1), rnd(43, 2, 6, 32, 32)
+    out = dict(k=net.k, k_cum=net.k_cum, theta_t=net.theta_t)
+    real = M.Gamma
+
+    class Injected:
+        count = 0
+
+        def __init__(self, conc, rate):
+            self.k, self.theta = conc, 1.0 / rate
+
+        def sample(self, shape):
+            n = rnd(500 + Injected.count, *shape, *self.k.shape)
+            Injected.count += 1
+            z = self.k * self.theta + 0.5 * n        # IEEE mul / add only: recomputable bit for bit on any host
+            Injected.raws.append(z.clone())
+            return z
+    for name, fn, kw in (("ddpm_gamma", M.ddpm_sampler, dict(subsample_steps=10)),
+                         ("ddpm_gamma_tmin", M.ddpm_sampler, dict(subsample_steps=10, t_min=0.35)),
+                         ("ddim_gamma_tmin", M.ddim_sampler, dict(subsample_steps=10, t_min=0.35))):
+        Injected.raws = []
+        M.Gamma = Injected
+        try:
+            out[name] = fn(x0.clone(), net, cond=cond, denoise=True, clip_before=True, final_only=True, log=False,
+                           gamma=True, **kw)
+        finally:
+            M.Gamma = real
+        # the raw draws are recomputable (``gamma_raw`` below, IEEE fp32 elementwise ops): keep their checksums only
+        out[name + "_raw_sums"] = torch.stack([r.double().sum() for r in Injected.raws])
+    save("sampler_gamma", **out)
+
+
+def gamma_raw(count, k, theta, shape):
+    """The injected stand-in for draw number ``count`` of ``gen_sampler_gamma``: k theta + n / 2, n = rnd(500 + count),
+    in fp32 with k / theta broadcast as full tensors, exactly as ``Injected.sample`` computes it."""
+    kk = torch.full(shape[1:], k)
+    th = 1.0 / torch.full(shape[1:], 1 / theta)
+    return kk * th + 0.5 * rnd(500 + count, *shape)
+
+
 def gen_forward_full():
     torch.set_num_threads(8)
     net, d = ref_net(192, 192, 128, 1234)
@@ -315,7 +363,8 @@ def gen_forward_spade():
     for k, v in p.items():
         assert tuple(own[k].shape) == tuple(v.shape), k
     missing, unexpected = net.load_state_dict(p, strict=False)
-    assert not unexpected and all(m in ("betas", "alphas", "alphas_prev", "unet.sigmas") for m in missing), missing
+    assert not unexpected and all(m in ("betas", "alphas", "alphas_prev", "unet.sigmas", "k", "k_cum", "theta_t")
+                                  for m in missing), missing
     x, cond = rnd(82, 2, 15, 32, 32), rnd(83, 2, 6, 32, 32)
     with torch.no_grad():
         o0 = net(x, torch.tensor([0, 0]), cond=cond)
@@ -330,7 +379,8 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     gens = dict(schedule=gen_schedule, fir=gen_fir, blocks=gen_blocks, forward_reduced=gen_forward_reduced,
-                samplers=gen_samplers, sampler_options=gen_sampler_options, forward_full=gen_forward_full, forward_full_b9=gen_forward_full_b9,
+                samplers=gen_samplers, sampler_options=gen_sampler_options, sampler_gamma=gen_sampler_gamma,
+                forward_full=gen_forward_full, forward_full_b9=gen_forward_full_b9,
                 traj_full=gen_traj_full, traj_fpndm_full=gen_traj_fpndm_full, unet_ddpm=gen_unet_ddpm, forward_spade=gen_forward_spade)
     for name, fn in gens.items():
         if a.only and name != a.only:

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, rnd
+from conftest import gamma_feed, golden, rnd
 
 pytestmark = pytest.mark.gpu
 
@@ -253,7 +253,7 @@ def test_sampler_options_t_min_and_frac_steps_against_reference_goldens():
     """``t_min`` > 0 (start from a clean frame: skip the early steps, noise the input to the first executed level) and
     ``frac_steps`` (only the last fraction of the un-subsampled schedule) of the DDPM / DDIM loops -- options no shipped
     config sets (models/__init__.py:248-277, :145-157) -- against the reference run with the same injected noise;
-    ``gamma`` stays NotImplementedError (needs model buffers mine.yml never builds)."""
+    ``gamma`` on a model built without the Gamma buffers is NotImplementedError."""
     import evc_amd  # noqa: F401
     from evc_amd import sampler
     g = golden("sampler_options")
@@ -270,10 +270,53 @@ def test_sampler_options_t_min_and_frac_steps_against_reference_goldens():
     assert rel(out, g["ddim_tmin"]) < 5e-4
     out = sampler.ddpm_sampler(x0, net, frac_steps=0.006, noise_fn=feed(int(g["ddpm_frac_noises_used"])), **kw)
     assert rel(out, g["ddpm_frac"]) < 5e-4
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):  # gamma noise needs a model built with config.model.gamma (next test)
         sampler.ddpm_sampler(x0, net, subsample_steps=10, gamma=True, **kw)
     with pytest.raises(IndexError):           # the reference indexes the subsampled tables by label here, and fails the same way
         sampler.ddpm_sampler(x0, net, subsample_steps=10, frac_steps=0.5, **kw)
+
+
+def test_sampler_gamma_noise_against_reference_goldens():
+    """``gamma=True`` (Gamma-distributed noise, models/__init__.py:119-153, :225-278, :321-324) on a model built with
+    ``config.model.gamma``: its k / k_cum / theta_t buffers equal to the reference's to 1 ulp (ncsnpp_more.py:744-749), and the
+    DDPM / DDIM runs against the reference fed the same raw draws.  The raw draws are ~1e4-1e5 with a spread of order 1
+    (fp32 quantises them at up to 0.016 -- in the reference too), so the centring must be the reference's fp32 subtraction."""
+    import evc_amd  # noqa: F401
+    from evc_amd import sampler
+    from evc_amd.scorenet import ScoreNet
+    from oracle.scorenet import Dims, seeded_params
+    g = golden("sampler_gamma")
+    cfg = make_config(32, 32, 32)
+    cfg.model.gamma = True
+    net = ScoreNet(cfg, seeded_params(Dims(ngf=32, n_head_channels=32, image_size=32), 41))
+    for name in ("k", "k_cum", "theta_t"):     # 1 ulp: the host's vectorised fp32 sqrt / cumsum differ between CPU generations
+        np.testing.assert_allclose(getattr(net, name).cpu().numpy(), g[name], rtol=5e-7, atol=0)
+        # ... and k theta ~ 1e5 is subtracted from draws with a spread of order 1, so 1 ulp of theta moves the noise by
+        # ~1 % (in the reference as well): the trajectories below run on the generating host's tables
+        setattr(net, name, torch.from_numpy(g[name].copy()))
+    x0, cond = rnd(46, 2, 15, 32, 32).clamp(-1, 1).cuda(), rnd(43, 2, 6, 32, 32).cuda()
+    steps = list(range(0, 1000, 100))
+    kw = dict(cond=cond, denoise=True, clip_before=True, final_only=True, subsample_steps=10, gamma=True)
+    first = 0
+    for name, fn, extra in (("ddpm_gamma", sampler.ddpm_sampler, {}), ("ddpm_gamma_tmin", sampler.ddpm_sampler, dict(t_min=0.35)),
+                            ("ddim_gamma_tmin", sampler.ddim_sampler, dict(t_min=0.35))):
+        feed, state, n = gamma_feed(g, name, first, net.k_cum.cpu(), net.theta_t.cpu(), steps)
+        state["first_step"] = 1
+        out = fn(x0, net, noise_fn=feed, **kw, **extra)
+        assert state["n"] == n, name
+        assert out.shape == g[name].shape and rel(out, g[name]) < 5e-4, name
+        first += n
+    # without injection the draw is torch's Gamma sampler on the device: finite, reproducible from the seed, and its
+    # standardised noise has the moments the schedule promises (mean 0; variance k theta^2 / (1 - alpha) ~ 1)
+    torch.manual_seed(5)
+    a = sampler.ddpm_sampler(x0, net, **kw)
+    torch.manual_seed(5)
+    b = sampler.ddpm_sampler(x0, net, **kw)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    i = 5
+    z = sampler._gamma_noise(torch.empty(64, 15, 32, 32, device="cuda"), net.k_cum[steps[i]], net.theta_t[steps[i]],
+                             net.alphas[steps[i]])
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.var()) - 1.0) < 0.1
 
 
 def test_sampler_label_sequences_match_reference():

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, rnd
+from conftest import gamma_feed, golden, rnd
 from oracle import samplers, schedule, scorenet, upfirdn2d
 from oracle.scorenet import Dims, seeded_params
 
@@ -114,6 +114,33 @@ def test_sampler_options_t_min_and_frac_steps():
     assert _rel(out.numpy(), g["ddim_tmin"]) < 1e-4
     out = samplers.ddpm(x0.clone(), eps, sched, frac_steps=0.006, noise_fn=feed(int(g["ddpm_frac_noises_used"])))
     assert _rel(out.numpy(), g["ddpm_frac"]) < 1e-4
+
+
+def test_sampler_gamma_noise_against_reference_goldens():
+    """``gamma=True`` of the DDPM / DDIM loops (models/__init__.py:119-153, :225-278, :321-324) and the model buffers it
+    reads (ncsnpp_more.py:744-749), against the reference run on a ``config.model.gamma`` model with the same raw draws."""
+    g = golden("sampler_gamma")
+    sched = schedule.base_schedule()
+    k, k_cum, theta_t = schedule.gamma_schedule(sched[0], sched[1])
+    for name, v in (("k", k), ("k_cum", k_cum), ("theta_t", theta_t)):       # bit-equal on the generating host; 1 ulp across CPUs
+        np.testing.assert_allclose(v.numpy(), g[name], rtol=5e-7, atol=0)
+    # k theta ~ 1e5 is subtracted from draws with a spread of order 1: 1 ulp of theta moves the noise by ~1 % (in the
+    # reference as well), so the trajectories run on the generating host's tables
+    k_cum, theta_t = torch.from_numpy(g["k_cum"].copy()), torch.from_numpy(g["theta_t"].copy())
+    d, p = _net(41)
+    x0, cond = rnd(46, 2, 15, 32, 32).clamp(-1, 1), rnd(43, 2, 6, 32, 32)
+    eps = lambda x, t: scorenet.forward(p, d, x, t, cond=cond)
+    steps = list(range(0, 1000, 100))
+    first_tmin = next(i for i, st in enumerate(steps) if not st < 0.35 * 10)     # len(alphas) is the SUBSAMPLED length (:145, :263)
+    first = 0
+    for name, fn, kw in (("ddpm_gamma", samplers.ddpm, {}), ("ddpm_gamma_tmin", samplers.ddpm, dict(t_min=0.35)),
+                         ("ddim_gamma_tmin", samplers.ddim, dict(t_min=0.35))):
+        feed, state, n = gamma_feed(g, name, first, k_cum, theta_t, steps)
+        state["first_step"] = first_tmin
+        out = fn(x0.clone(), eps, sched, subsample_steps=10, noise_fn=feed, gamma=(k_cum, theta_t), **kw)
+        assert state["n"] == n
+        assert _rel(out.numpy(), g[name]) < 1e-4, name
+        first += n
 
 
 def test_label_sequences():

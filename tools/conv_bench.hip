@@ -12,6 +12,21 @@
 
 struct Shape { int B, R, Ci, Co, K; int mode; };
 
+// Clock probe (layout 9): one wave on a second stream, concurrent with the convolutions.  out[0] = s_memtime ticks, out[1] = 100 MHz
+// s_memrealtime ticks over the same interval, out[2] = realtime ticks a chain of `n` x 64 dependent v_add_f32 took (4 cycles each when the
+// wave issues unhindered: a LOWER bound of the shader clock while other waves compete for the SIMD's issue slot).
+__global__ void clock_probe_kernel(unsigned long long* out, int n) {
+    const unsigned long long r0 = wall_clock64(), c0 = clock64();
+    float v = (float)threadIdx.x;
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int j = 0; j < 64; ++j) asm volatile("v_add_f32 %0, %0, %0" : "+v"(v));
+    }
+    const unsigned long long r1 = wall_clock64(), c1 = clock64();
+    if (v == 123.f) out[3] = 1;
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; out[2] = (unsigned long long)n * 64; }
+}
+
 int main(int argc, char** argv) {
     const int layout = argc > 1 ? atoi(argv[1]) : 0;
     const int iters = argc > 2 ? atoi(argv[2]) : 10;
@@ -77,6 +92,57 @@ int main(int argc, char** argv) {
                    (M + 127) / 128, evc_conv_co_pad(q.Co) / (64 * pick_tn(evc_conv_co_pad(q.Co))), def_tm, def_splits, deftf, btm, bsp, best, line);
             fflush(stdout);
             hipFree(x); hipFree(wraw); hipFree(o); hipFree(ca); hipFree(cs); hipFree(wp); hipFree(ws);
+        }
+        return 0;
+    }
+    if (layout == 9) {
+        // fixed cost per pixel tile: 128x128 -> 192 channels, 3x3 gn+silu, 128-pixel tiles only, unsplit; the input width sweeps the
+        // K loop from 3 to 144 macro-steps, the batch the number of rounds (B=4: one workgroup per CU, 8: two, 16: two rounds of two)
+        g_wide_tiles = 0; g_tail_split = 0;
+        const int cis[] = {16, 48, 96, 192, 384, 768};
+        const int bs[] = {4, 8};
+        const int only_ci = argc > 4 ? atoi(argv[4]) : 0, only_b = argc > 5 ? atoi(argv[5]) : 0;     // 5th / 6th argument: one input width / batch
+        for (int B : bs) for (int Ci : cis) {
+            if ((only_ci && Ci != only_ci) || (only_b && B != only_b)) continue;
+            const int R = 128, Co = 192;
+            const size_t nx = (size_t)B * R * R * Ci, no = (size_t)B * R * R * Co, nraw = (size_t)Co * Ci * 9;
+            float *x, *wraw, *o, *ca, *cs; void* wp;
+            CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&wraw, nraw * 4)); CK(hipMalloc(&o, no * 4));
+            CK(hipMalloc(&ca, (size_t)B * Ci * 4)); CK(hipMalloc(&cs, (size_t)B * Ci * 4));
+            CK(hipMemset(x, 0x3c, nx * 4)); CK(hipMemset(wraw, 0x3b, nraw * 4)); CK(hipMemset(ca, 0x3c, (size_t)B * Ci * 4)); CK(hipMemset(cs, 0x3b, (size_t)B * Ci * 4));
+            if (only != 0) {        // 4th argument 0: constant operands (the chip then holds a higher clock: fewer bits toggle); default: random
+                std::vector<float> h(std::max(nx, nraw));
+                for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((int)((i * 2654435761u) >> 8 & 0xffff) - 32768) / 32768.0f;
+                CK(hipMemcpy(x, h.data(), nx * 4, hipMemcpyHostToDevice));
+                for (size_t i = 0; i < nraw; ++i) h[i] *= 0.02f;
+                CK(hipMemcpy(wraw, h.data(), nraw * 4, hipMemcpyHostToDevice));
+                std::vector<float> one((size_t)B * Ci, 1.0f), zero((size_t)B * Ci, 0.1f);
+                CK(hipMemcpy(ca, one.data(), one.size() * 4, hipMemcpyHostToDevice));
+                CK(hipMemcpy(cs, zero.data(), zero.size() * 4, hipMemcpyHostToDevice));
+            }
+            CK(hipMalloc(&wp, (size_t)evc_conv_packed_bytes(Co, Ci, 3, 3, 2)));
+            evc_conv_pack_weights(wraw, wp, Co, Ci, 3, 3, 2, nullptr);
+            evc_conv_args a = {};
+            a.src0 = x; a.C0 = Ci; a.w_packed = (const float*)wp; a.out = o; a.ld_out = Co; a.out_scale = 1.f;
+            a.B = B; a.H = R; a.W = R; a.Co = Co; a.KH = 3; a.KW = 3; a.arith = 2; a.splits = 1;
+            a.coef_a = ca; a.coef_s = cs; a.act_in = EVC_ACT_SILU;
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            for (int i = 0; i < 2; ++i) if (evc_conv2d_nhwc_f32(&a, nullptr, nullptr) != 0) { printf("launch failed\n"); return 1; }
+            static hipStream_t s2 = nullptr; static unsigned long long* pr = nullptr;
+            if (!s2) { CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); CK(hipHostMalloc(&pr, 64)); }
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < iters; ++i) {
+                evc_conv2d_nhwc_f32(&a, nullptr, nullptr);
+                if (i == iters / 4) hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, s2, pr, 2000);   // ~0.25 ms at 2 GHz
+            }
+            CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1)); CK(hipStreamSynchronize(s2));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+            printf("B=%2d 128x128 %4d->192 k3 gn+silu unsplit 128-px tiles: %4d macro-steps  %8.1f us  %6.1f TF/s | probe: s_memtime %.3f GHz, "
+                   "v_add chain >= %.3f GHz over %.0f us\n", B, Ci, 3 * Ci / 16, ms * 1e3, 2.0 * B * R * R * (double)Ci * Co * 9 / ms / 1e9,
+                   (double)pr[0] / (double)pr[1] * 0.1, 4.0 * (double)pr[2] / (double)pr[1] * 0.1, (double)pr[1] / 100.0);
+            fflush(stdout);
+            hipFree(x); hipFree(wraw); hipFree(o); hipFree(ca); hipFree(cs); hipFree(wp);
         }
         return 0;
     }
