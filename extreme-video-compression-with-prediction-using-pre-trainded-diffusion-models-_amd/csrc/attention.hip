@@ -494,8 +494,17 @@ AttnPlan attention_plan_f16(int B, int heads, int N) {
     const int ntiles = (N + 31) / 32;
     p.waves = N >= 128 ? 4 : (N >= 64 ? 2 : 1);
     const long long qblocks = (N + 32 * p.waves - 1) / (32 * p.waves);
+    // key parts: the count that minimises rounds x tiles per part (two 56-KB workgroups fit a CU: 512 slots), each part
+    // charged 0.3 tile-times for its share of the merge.  B=9, 32x32, 2 heads: 144 query blocks -> 3 parts (432 workgroups,
+    // one round of 11 tiles) instead of 4 (576 workgroups = 2 rounds of 8).
     p.kparts = 1;
-    while (p.kparts < 8 && bh * qblocks * p.kparts < EVC_ATTN_WG_TARGET && ntiles / (p.kparts * 2) >= 2) p.kparts *= 2;
+    double best = 1e30;
+    for (int kp = 1; kp <= 8; ++kp) {
+        if (kp > 1 && ntiles / kp < 2) break;
+        const long long wgs = bh * qblocks * kp;
+        const double cost = (double)((wgs + EVC_ATTN_WG_TARGET - 1) / EVC_ATTN_WG_TARGET) * ((ntiles + kp - 1) / kp) + (kp > 1 ? 0.3 * kp : 0.0);
+        if (cost < best - 1e-9) { best = cost; p.kparts = kp; }
+    }
     p.tiles_per_part = (ntiles + p.kparts - 1) / p.kparts;
     p.kparts = (ntiles + p.tiles_per_part - 1) / p.tiles_per_part;
     return p;
