@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
     const int layout = argc > 1 ? atoi(argv[1]) : 0;
     const int iters = argc > 2 ? atoi(argv[2]) : 10;
     const int only = argc > 3 ? atoi(argv[3]) : -1;
-    const bool skip_f32 = layout == 5 || layout == 6 || layout == 8;         // layout 5: split arithmetics only (faster A/B)
+    const bool skip_f32 = layout == 4 || layout == 5 || layout == 6 || layout == 8;         // layout 5: split arithmetics only (faster A/B)
     (void)layout;
     std::vector<Shape> shapes = {{8, 128, 192, 192, 3, 0}, {8, 128, 192, 192, 3, 1}, {9, 128, 192, 192, 3, 1},
                                  {8, 128, 384, 192, 3, 1}, {8, 64, 384, 384, 3, 0}, {8, 64, 384, 384, 3, 1},
