@@ -216,7 +216,10 @@ def roofline_leg(net, clips, device):
                        for (a, t), v in sorted(per.items())}
     out["batch"] = clips
     out["note"] = ("launch durations measured with the res-block side stream OFF (launches one after another; the timed region "
-                   "runs with it on); `families` / conv_ms_per_forward include the split-K combine launches")
+                   "runs with it on); `families` / conv_ms_per_forward include the split-K combine launches; under sustained "
+                   "launches of this kernel the package sits at its 1 400 W power cap at 1.83 GHz (profiles/r03_power_cap.log), "
+                   "63 % of the energy in the MFMAs (profiles/r03_conv_mfma_count_ablation.log): frac is bounded by energy per "
+                   "product, not by issue slots")
     return out
 
 
