@@ -117,10 +117,11 @@ def roofline_leg(net, clips, device):
     tf0 = time.perf_counter()
     net.forward_label(x, 500, c)
     torch.cuda.synchronize()
-    probe = L.ClockProbe(int(max(1.0, 0.8 * reps * (time.perf_counter() - tf0) * 1e3) * 1e3), device)   # spans ~80 % of the forwards below
+    probe = L.ClockProbe(int(max(1.0, 2.0 * reps * (time.perf_counter() - tf0) * 1e3) * 1e3), device)   # ends with the forwards below
     prof.clear()
     for _ in range(reps):
         net.forward_label(x, 500, c)
+    probe.stop()
     L.CONV_PROFILE = None
     torch.cuda.synchronize()
     live_clock = probe.ghz()
@@ -445,11 +446,13 @@ def main():
     D.barrier()
     torch.cuda.synchronize()
     # shader clock the chip holds during the timed region (it runs into the package power cap under the convolutions): an
-    # idle one-wave probe on its own stream, sized from the warm-up step so that it ends well inside the region
-    probe = L.ClockProbe(int(min(2.0, 0.5 * t_warm * a.steps) * 1e6), device) if (rank == 0 and t_warm) else None
+    # idle one-wave probe on its own stream that ends with the region (or after 9 s of it)
+    probe = L.ClockProbe(int(min(9.0, t_warm * a.steps) * 1e6), device) if (rank == 0 and t_warm) else None
     t0 = time.perf_counter()
     for _ in range(a.steps):
         frames = step()
+    if probe is not None:
+        probe.stop()                                  # stream-ordered behind the last step: the probe never outlives the region
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0            # this rank's own time, before it waits for the others
     power_w = L.gpu_power_w(device) if rank == 0 else None     # the driver's ~1 s average at the end of the last step

@@ -76,7 +76,7 @@ HIP_SYMBOLS = {
     "evc_version": (c_char_p, []),
     "evc_arch": (c_char_p, []),
     "evc_device_ok": (c_int, []),
-    "evc_clock_probe": (c_int, [c_void_p, c_int, c_void_p]),
+    "evc_clock_probe": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "evc_upfirdn2d_f32": (c_int, [c_void_p, c_void_p, POINTER(c_float)] + [c_int] * 13 + [c_void_p]),
     "evc_upfirdn2d_nhwc_f32": (c_int, [c_void_p, c_void_p, POINTER(c_float)] + [c_int] * 10 +
                                [c_void_p, c_void_p, c_int, c_void_p]),
@@ -322,19 +322,29 @@ def range_events(device=None, reset=False):
 
 
 class ClockProbe:
-    """Shader clock held by the chip over the next ``spin_us`` microseconds, measured by a one-wave idle kernel on its own
-    stream (``evc_clock_probe``): start it, run the work to be characterised on other streams, then read ``ghz()``."""
+    """Shader clock held by the chip while other streams work, measured by a one-wave idle kernel on its own stream
+    (``evc_clock_probe``): start it, enqueue the work to be characterised, call ``stop()`` (a stream-ordered write behind that
+    work on the CURRENT stream: the probe ends with it, or after ``max_us`` at the latest), then read ``ghz()``."""
 
-    def __init__(self, spin_us, device=None):
+    def __init__(self, max_us, device=None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.out = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.stream = torch.cuda.Stream(device=self.device)
-        _check(hip_lib().evc_clock_probe(self.out.data_ptr(), int(spin_us), self.stream.cuda_stream), "evc_clock_probe")
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))          # the two zero-fills above
+        _check(hip_lib().evc_clock_probe(self.out.data_ptr(), int(max_us), self.flag.data_ptr(), self.stream.cuda_stream),
+               "evc_clock_probe")
+
+    def stop(self):
+        self.flag.fill_(1)
 
     def ghz(self):
         self.stream.synchronize()
         ticks, ref = (int(v) for v in self.out.tolist())
         return ticks / ref * 0.1 if ref else None
+
+    def seconds(self):
+        return int(self.out[1]) / 1e8
 
 
 def gpu_power_w(device=None):

@@ -48,11 +48,13 @@ const char* evc_version(void);
 const char* evc_arch(void);
 int evc_device_ok(void);
 
-/* Measurement aid (bench.py): a one-wave kernel on `stream` that idles for spin_us microseconds (<= 10 s) and writes
- * out2[0] = shader-clock ticks (s_memtime), out2[1] = 100 MHz reference ticks (s_memrealtime) elapsed meanwhile;
- * out2 is device or pinned host memory.  out2[0] / out2[1] / 10 = the shader clock in GHz the chip held while other
- * streams ran -- the convolution kernels run the package into its power cap, so this is what the roofline's clock is. */
-int evc_clock_probe(unsigned long long* out2, int spin_us, void* stream);
+/* Measurement aid (bench.py): a one-wave kernel on `stream` that idles for at most spin_us microseconds (<= 10 s), or until
+ * the device word *stop (may be NULL) becomes non-zero -- the caller writes it stream-ordered behind the work it wants
+ * characterised, so the probe never outlives that work -- and writes out2[0] = shader-clock ticks (s_memtime), out2[1] =
+ * 100 MHz reference ticks (s_memrealtime) elapsed meanwhile; out2 is device or pinned host memory.  out2[0] / out2[1] / 10
+ * = the shader clock in GHz the chip held while other streams ran -- the convolution kernels run the package into its
+ * power cap, so this is what the roofline's clock is. */
+int evc_clock_probe(unsigned long long* out2, int spin_us, const unsigned* stop, void* stream);
 
 /* ---- upfirdn2d: the reference's own native op ---------------------------------------------
  * Replaces pybind `upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0,

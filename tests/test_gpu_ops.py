@@ -703,20 +703,22 @@ def test_elic_checkerboard_gather_scatter(L):
 
 def test_clock_probe_reports_a_plausible_shader_clock():
     """``evc_clock_probe`` (bench.py's held-clock measurement): an idle wave counts shader-clock and 100 MHz reference ticks
-    over the requested interval; the ratio is a clock the chip can run at, and the interval is the one asked for."""
+    until the work enqueued behind it is done (stream-ordered stop word) or its time limit; the ratio is a clock the chip can
+    run at."""
     import evc_amd  # noqa: F401
     from evc_amd import lib as L
-    import time
-    t0 = time.perf_counter()
-    pr = L.ClockProbe(20000)                     # 20 ms
+    pr = L.ClockProbe(2_000_000)                 # at most 2 s ...
     x = torch.randn(1 << 22, device="cuda")
-    for _ in range(20):
-        x = L.scale_clamp(x, 1.0001, 0.0)        # something on another stream meanwhile
+    for _ in range(200):
+        x = L.scale_clamp(x, 1.0001, 0.0)        # ... but it ends with this work
+    pr.stop()
+    torch.cuda.synchronize()
     ghz = pr.ghz()
-    dt = time.perf_counter() - t0
-    ticks, ref = (int(v) for v in pr.out.tolist())
-    assert 19e-3 <= ref / 1e8 <= 40e-3 and dt >= 19e-3
+    assert 1e-4 < pr.seconds() < 0.5, pr.seconds()
     assert 0.1 < ghz < 2.6, ghz                  # MI355X: idle ~0.1-0.2 GHz, peak 2.4 GHz
+    lim = L.ClockProbe(20000)                    # never stopped: runs to its 20 ms limit
+    assert 0.019 <= (lim.ghz() and lim.seconds()) <= 0.04
     p = L.gpu_power_w()
     assert p is None or 50 < p < 1500
-    assert L.hip_lib().evc_clock_probe(None, 10, None) != 0 and L.hip_lib().evc_clock_probe(pr.out.data_ptr(), 0, None) != 0
+    assert L.hip_lib().evc_clock_probe(None, 10, None, None) != 0
+    assert L.hip_lib().evc_clock_probe(pr.out.data_ptr(), 0, None, None) != 0
