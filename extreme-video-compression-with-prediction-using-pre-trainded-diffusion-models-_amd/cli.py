@@ -52,7 +52,9 @@ def build_parser():
                    help="psnr policy: dB thresholds; lpips policy: distances (default: the reference's sweep "
                         "0.30, 0.29 ... 0.03, city_sender.py:508)")
     p.add_argument("--metric", type=str, default=None,
-                   help="lpips policy: package.module:callable, fn(pred, gt) -> distances for (n,3,H,W) tensors in [0,1]")
+                   help="lpips policy: weight files of the HIP LPIPS-AlexNet, 'alexnet-owt-*.pth,alex.pth' (torchvision backbone + "
+                        "lpips v0.1 linear layers) or one saved LPIPS state dict; or package.module:callable, fn(pred, gt) -> "
+                        "distances for (n,3,H,W) tensors in [0,1]")
     p.add_argument("--policy-batch", type=int, default=32,
                    help="psnr / lpips policy: (video, q, threshold) jobs stacked per score-network launch")
     p.add_argument("--bpp-limit", type=float, default=1.0,

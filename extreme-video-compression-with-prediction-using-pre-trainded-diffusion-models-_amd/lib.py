@@ -77,6 +77,9 @@ HIP_SYMBOLS = {
     "evc_arch": (c_char_p, []),
     "evc_device_ok": (c_int, []),
     "evc_clock_probe": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "evc_im2col_nchw_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p]),
+    "evc_maxpool3s2_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "evc_lpips_layer_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "evc_upfirdn2d_f32": (c_int, [c_void_p, c_void_p, POINTER(c_float)] + [c_int] * 13 + [c_void_p]),
     "evc_upfirdn2d_nhwc_f32": (c_int, [c_void_p, c_void_p, POINTER(c_float)] + [c_int] * 10 +
                                [c_void_p, c_void_p, c_int, c_void_p]),
@@ -319,6 +322,33 @@ def range_events(device=None, reset=False):
     if reset:
         w.zero_()
     return v
+
+
+def im2col_nchw(x, KH, KW, stride, pad, ld_out, shift=None, scale=None):
+    """x: (N, C, H, W) -> (N, Ho, Wo, ld_out) patch rows in (c, ky, kx) order, zero-filled beyond C*KH*KW; optional
+    (x - shift[c]) / scale[c] before the zero padding (include/evc_hip.h)."""
+    N, C, H, W = x.shape
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    out = torch.empty((N, Ho, Wo, ld_out), device=x.device, dtype=torch.float32)
+    _check(hip_lib().evc_im2col_nchw_f32(fptr(x), fptr(out), N, C, H, W, KH, KW, stride, pad, ld_out, ptr(shift), ptr(scale),
+                                         stream_ptr()), "evc_im2col_nchw_f32")
+    return out
+
+
+def maxpool3s2_nhwc(x):
+    N, H, W, C = x.shape
+    out = torch.empty((N, (H - 3) // 2 + 1, (W - 3) // 2 + 1, C), device=x.device, dtype=torch.float32)
+    _check(hip_lib().evc_maxpool3s2_nhwc_f32(fptr(x), fptr(out), N, H, W, C, stream_ptr()), "evc_maxpool3s2_nhwc_f32")
+    return out
+
+
+def lpips_layer(f0, f1, lin_w, dist, accumulate):
+    """dist[n] (+)= spatial mean of lin_w . (unit-normalised f0 - unit-normalised f1)^2; f0, f1: (N, H, W, C)."""
+    N, H, W, C = f0.shape
+    assert f1.shape == f0.shape and lin_w.numel() == C and dist.numel() == N
+    _check(hip_lib().evc_lpips_layer_f32(fptr(f0), fptr(f1), fptr(lin_w), fptr(dist), N, H * W, C, int(bool(accumulate)),
+                                         stream_ptr()), "evc_lpips_layer_f32")
+    return dist
 
 
 class ClockProbe:

@@ -62,13 +62,22 @@ class CallableMetric:
 
 
 def load_metric(policy, spec=None, device="cuda"):
-    """``psnr`` -> PsnrMetric; ``lpips`` -> CallableMetric around ``spec`` = "package.module:callable" (called as
-    fn(pred, gt)), or around the ``lpips`` package (LPIPS(net='alex'), inputs scaled to [-1, 1] as lpips expects --
+    """``psnr`` -> PsnrMetric; ``lpips`` -> the HIP LPIPS-AlexNet (``lpips.LpipsAlex``) when ``spec`` names its weight files
+    ("alexnet.pth,alex.pth" or one saved LPIPS state dict), else a CallableMetric around ``spec`` = "package.module:callable"
+    (called as fn(pred, gt)), or around the ``lpips`` package (LPIPS(net='alex'), inputs scaled to [-1, 1] as lpips expects --
     the reference feeds [0, 1] frames unnormalised, city_sender.py:389-390; pass your own callable to reproduce that)."""
     if policy == "psnr":
         return PsnrMetric()
     if policy != "lpips":
         raise ValueError(f"unknown policy metric {policy!r}")
+    if spec and ".pt" in spec:
+        # weight files: "alexnet-owt-*.pth,alex.pth" (torchvision backbone + lpips v0.1 linear layers) or one file holding
+        # a saved lpips.LPIPS state dict -> the HIP implementation (lpips.py); frames are passed as they are, like the reference
+        from .lpips import LpipsAlex
+        paths = spec.split(",")
+        net = (LpipsAlex.from_files(paths[0], paths[1], device) if len(paths) == 2 else
+               LpipsAlex(torch.load(paths[0], map_location="cpu", weights_only=True), device))
+        return CallableMetric(lambda a, b: net(a, b), name="lpips-alex-hip")
     if spec:
         mod, _, attr = spec.partition(":")
         fn = getattr(importlib.import_module(mod), attr or "metric")

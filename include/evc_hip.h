@@ -299,6 +299,24 @@ long long evc_conv5x5s2_workspace_bytes(int B, int Ho, int Wo, int Ci);
 int evc_conv5x5s2_f32(const float* x, int ld_in, const void* w_packed, int arith, const float* bias, float* out, float* ws,
                       int B, int Ho, int Wo, int Ci, int Co, int act_out, void* stream);
 
+/* ---- LPIPS (AlexNet, v0.1): the perceptual distance of the sender's decision rule ------------------------------
+ * Replaces lpips.LPIPS(net='alex') as built by city_sender.py:302 and called by decide_5to5_lpips (:376-406).  The
+ * metric is third-party code (lpips==0.1.4, requirements.txt:66, on torchvision's AlexNet; neither is in the reference
+ * tree): its published algorithm is restated in oracle/lpips.py.  The five convolutions run on evc_conv2d_nhwc_f32; these
+ * are the other pieces (csrc/lpips.hip):
+ *   evc_im2col_nchw_f32   x (N, C, H, W) NCHW -> out (N, Ho, Wo, ld_out) rows of KH*KW patches in (c, ky, kx) order, the
+ *                         columns C*KH*KW .. ld_out-1 zero; optional per-channel (x - shift[c]) / scale[c] (the ScalingLayer)
+ *                         applied before the zero padding, as the convolution that follows would see it.  Ho = (H + 2 pad -
+ *                         KH) / stride + 1.  Turns the stride-4 11x11 first convolution into a 1x1 convolution.
+ *   evc_maxpool3s2_nhwc_f32   MaxPool2d(3, stride 2), no padding, floor: (N, H, W, C) -> (N, (H-3)/2+1, (W-3)/2+1, C), C % 4 == 0.
+ *   evc_lpips_layer_f32   one feature tap: dist[n] (+)= mean over pixels of sum_c lin_w[c] * (f0/(|f0|_2 + 1e-10) -
+ *                         f1/(|f1|_2 + 1e-10))^2, norms over the channels of a pixel; f0, f1: (N, HW, C) NHWC. */
+int evc_im2col_nchw_f32(const float* x, float* out, int N, int C, int H, int W, int KH, int KW, int stride, int pad, int ld_out,
+                        const float* shift, const float* scale, void* stream);
+int evc_maxpool3s2_nhwc_f32(const float* x, float* out, int N, int H, int W, int C, void* stream);
+int evc_lpips_layer_f32(const float* f0, const float* f1, const float* lin_w, float* dist, int N, int HW, int C, int accumulate,
+                        void* stream);
+
 /* ---- GDN (not on the decode path: g_s / g_a contain none) ---------------------------------
  * y = x * rsqrt(beta + gamma . x^2) (inverse: * sqrt) -- GDN.forward, ELICUtilis/layers/gdn.py:62-77; simplified != 0:
  * y = x / (beta + gamma . |x|) -- GDN1.forward, :95-106.  x, out: NHWC with C % 16 == 0; gamma_packed = the

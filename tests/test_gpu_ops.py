@@ -722,3 +722,88 @@ def test_clock_probe_reports_a_plausible_shader_clock():
     assert p is None or 50 < p < 1500
     assert L.hip_lib().evc_clock_probe(None, 10, None, None) != 0
     assert L.hip_lib().evc_clock_probe(pr.out.data_ptr(), 0, None, None) != 0
+
+
+def test_im2col_and_maxpool_against_torch():
+    """The two non-convolution layers of the LPIPS backbone: stride-4 11x11 patches (ScalingLayer fused, zero padding after
+    the scaling, zero fill to the padded row length) vs ``F.unfold``; MaxPool2d(3, 2) vs ``F.max_pool2d``, odd sizes included."""
+    import torch.nn.functional as F
+    import evc_amd  # noqa: F401
+    from evc_amd import lib as L
+    x = rnd(11, 3, 3, 37, 45)
+    shift, scale = torch.tensor([-0.03, -0.088, -0.188]), torch.tensor([0.458, 0.448, 0.45])
+    got = L.im2col_nchw(x.cuda(), 11, 11, 4, 2, 368, shift.cuda(), scale.cuda()).cpu()
+    xs = (x - shift.view(1, 3, 1, 1)) / scale.view(1, 3, 1, 1)
+    ref = F.unfold(xs, kernel_size=11, stride=4, padding=2)                      # (N, 363, L), (c, ky, kx) order
+    Ho, Wo = (37 + 4 - 11) // 4 + 1, (45 + 4 - 11) // 4 + 1
+    assert got.shape == (3, Ho, Wo, 368)
+    np.testing.assert_allclose(got[..., :363].reshape(3, Ho * Wo, 363).numpy(), ref.transpose(1, 2).numpy(), rtol=1e-6, atol=1e-6)
+    assert float(got[..., 363:].abs().max()) == 0.0
+    plain = L.im2col_nchw(x.cuda(), 3, 5, 2, 1, 48).cpu()                       # no scaling layer, rectangular kernel
+    ref = F.unfold(x, kernel_size=(3, 5), stride=2, padding=1)
+    np.testing.assert_array_equal(plain[..., :45].reshape(3, -1, 45).numpy(), ref.transpose(1, 2).numpy())
+    for H, W in ((31, 31), (15, 15), (8, 13)):
+        f = rnd(12, 2, 64, H, W)
+        got = L.maxpool3s2_nhwc(f.permute(0, 2, 3, 1).contiguous().cuda()).cpu().permute(0, 3, 1, 2)
+        np.testing.assert_array_equal(got.numpy(), F.max_pool2d(f, 3, 2).numpy())
+
+
+def test_lpips_alexnet_against_the_oracle():
+    """LPIPS(net='alex') (city_sender.py:302, :376-406) on the HIP kernels vs the CPU restatement of the lpips 0.1.4 /
+    torchvision algorithm (oracle/lpips.py; PARITY UNPINNED: neither package nor its weights exist here) in float64, seeded
+    stand-in weights in the packages' own layouts: per-pair distances, the single-frame call form of the reference, d(x, x) = 0,
+    the key spellings of a saved LPIPS module."""
+    import evc_amd  # noqa: F401
+    from evc_amd.lpips import LpipsAlex
+    from oracle import lpips as OL
+    sd = OL.seeded_state_dict(5)
+    net = LpipsAlex(sd)
+    a = torch.rand(5, 3, 128, 128, generator=torch.Generator().manual_seed(1))
+    b = (a + 0.1 * rnd(2, 5, 3, 128, 128)).clamp(0, 1)
+    want = OL.distance({k: v.double() for k, v in sd.items()}, a.double(), b.double()).numpy()
+    got = net(a.cuda(), b.cuda()).cpu().numpy()
+    assert got.shape == (5,) and np.all(want > 1e-5)
+    np.testing.assert_allclose(got, want, rtol=2e-4)
+    one = net(a[2].cuda(), b[2].cuda())                                        # decide_5to5_lpips passes (3, H, W) frames
+    assert one.shape == (1,) and abs(float(one) - want[2]) <= 2e-4 * want[2]
+    assert float(net(a.cuda(), a.cuda()).abs().max()) == 0.0
+    taps = net.features(a.cuda())
+    ref_taps = OL.features(sd, a)
+    for t, r in zip(taps, ref_taps):
+        r = r.permute(0, 2, 3, 1).numpy()
+        assert t.shape == r.shape and float(np.abs(t.cpu().numpy() - r).max()) <= 2e-5 * float(np.abs(r).max())
+    renamed = {}
+    for k, v in sd.items():
+        if k.startswith("features."):
+            idx = int(k.split(".")[1])
+            renamed[{0: "net.slice1.0", 3: "net.slice2.3", 6: "net.slice3.6", 8: "net.slice4.8", 10: "net.slice5.10"}[idx] + "." + k.split(".")[2]] = v
+        else:
+            renamed["lins." + k[3:]] = v
+    np.testing.assert_array_equal(LpipsAlex(renamed)(a.cuda(), b.cuda()).cpu().numpy(), got)
+    with pytest.raises(KeyError):
+        LpipsAlex({k: v for k, v in sd.items() if not k.startswith("lin3")})
+
+
+def test_lpips_policy_metric_from_weight_files(tmp_path):
+    """``--policy lpips --metric alexnet.pth,alex.pth``: the two weight files of the packages (here: seeded stand-ins saved in
+    their layouts) load through the weights-only loader into the HIP metric, which then drives the reference's accept rule
+    (distance <= threshold, decide_5to5_lpips)."""
+    import evc_amd  # noqa: F401
+    from evc_amd import policy as P
+    from oracle import lpips as OL
+    sd = OL.seeded_state_dict(6)
+    torch.save({k: v for k, v in sd.items() if k.startswith("features.")}, tmp_path / "alexnet.pth")
+    torch.save({k: v for k, v in sd.items() if k.startswith("lin")}, tmp_path / "alex.pth")
+    m = P.load_metric("lpips", f"{tmp_path / 'alexnet.pth'},{tmp_path / 'alex.pth'}", "cuda")
+    gt = torch.rand(4, 3, 128, 128, generator=torch.Generator().manual_seed(3))
+    pred = gt.clone()
+    pred[1:] += 0.05 * rnd(4, 3, 3, 128, 128)
+    pred[3] = torch.rand(3, 128, 128, generator=torch.Generator().manual_seed(4))
+    v = m.values(pred.cuda(), gt.cuda())
+    want = OL.distance(sd, pred, gt).numpy()
+    np.testing.assert_allclose(v, want, rtol=1e-3, atol=1e-7)
+    assert v[0] == 0.0 and v[3] > v[1] > 0
+    thr = float((v[2] + v[3]) / 2)
+    assert [bool(m.accept(x, thr)) for x in v] == [True, True, True, False]
+    torch.save(sd, tmp_path / "both.pth")                                       # one file holding everything
+    np.testing.assert_array_equal(P.load_metric("lpips", str(tmp_path / "both.pth"), "cuda").values(pred.cuda(), gt.cuda()), v)

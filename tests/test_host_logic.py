@@ -182,3 +182,19 @@ def test_policy_metrics_hook_and_rd_envelope():
     env2 = P.rd_envelope(bpp, lp, False)
     assert env2.shape[0] == 2 and 0.28 not in env2[1] and 0.10 in env2[1]
     assert P.rd_envelope([0.1], [30.0], True).shape == (2, 1)       # a fixed-mask run has a single point
+
+
+def test_lpips_oracle_basic_properties():
+    """oracle/lpips.py (the restated lpips 0.1.4 / torchvision AlexNet algorithm the HIP metric is checked against): tap shapes
+    of a 128x128 frame, zero distance of identical images, symmetry, growth with the perturbation."""
+    import torch
+    from oracle import lpips as OL
+    sd = OL.seeded_state_dict(5)
+    x = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(0))
+    taps = OL.features(sd, x)
+    assert [tuple(t.shape[1:]) for t in taps] == [(64, 31, 31), (192, 15, 15), (384, 7, 7), (256, 7, 7), (256, 7, 7)]
+    assert float(OL.distance(sd, x, x).abs().max()) == 0.0
+    n = torch.randn(2, 3, 128, 128, generator=torch.Generator().manual_seed(1))
+    d1, d2 = OL.distance(sd, x, x + 0.02 * n), OL.distance(sd, x, x + 0.2 * n)
+    assert bool((d2 > d1).all()) and bool((d1 > 0).all())
+    assert torch.allclose(OL.distance(sd, x, x + 0.2 * n), OL.distance(sd, x + 0.2 * n, x), rtol=1e-5)
