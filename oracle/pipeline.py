@@ -31,10 +31,13 @@ def generate_chunk(p_net, d_net, prev2, subsample, noise_fn, chunk_id):
     return ((x[0] + 1.0) / 2.0).clamp(0.0, 1.0).reshape(5, C, H, W)             # inverse_data_transform
 
 
-def run_clip(p_net, d_net, p_elic, gt, threshold, subsample, noise_fn, patch=64, coder=None, frames=30, trace=None):
+def run_clip(p_net, d_net, p_elic, gt, threshold, subsample, noise_fn, patch=64, coder=None, frames=30, trace=None,
+             distance=None):
     """One (video, q, threshold) job of the reference's sweep.  gt: (frames,3,H,W) float in [0,1].
     Returns dict(x (frames,3,H,W), d (frames,), bits [per key frame], bpp, psnr [per frame]).  ``trace``: optional list
-    that receives every PSNR the accept / reject rule looked at (tests use it to keep thresholds away from ties)."""
+    that receives every value the accept / reject rule looked at (tests use it to keep thresholds away from ties).
+    ``distance``: None = decide_5to5 (PSNR, kept while >= threshold, city_sender.py:353-374); a callable
+    (pred_frame, gt_frame) -> float = decide_5to5_lpips (kept while <= threshold, :376-406)."""
     kw = {} if coder is None else {"coder": coder}
     x, d, bits = [], [], []
 
@@ -49,10 +52,10 @@ def run_clip(p_net, d_net, p_elic, gt, threshold, subsample, noise_fn, patch=64,
         chunk += 1
         acc = 0
         for t in range(min(5, frames - l)):                                         # decide_5to5: accepted prefix
-            v = cal_psnr(pred[t].numpy(), gt[l + t].numpy())
+            v = cal_psnr(pred[t].numpy(), gt[l + t].numpy()) if distance is None else float(distance(pred[t], gt[l + t]))
             if trace is not None:
                 trace.append(v)
-            if v < threshold:
+            if (v < threshold) if distance is None else (v > threshold):
                 break
             x.append(pred[t]); d.append(0); acc += 1
         if acc == 0:                                                                # :538-548: two more key frames

@@ -146,13 +146,11 @@ def test_batched_policy_sweep_equals_one_job_at_a_time():
     assert env.shape[0] == 2 and 1 <= env.shape[1] <= len(many[(0, 3)])
 
 
-def test_policy_sweep_against_the_oracle_sender_loop():
-    """SURVEY.md 8f item 2 against an ORACLE (not against itself): ``policy.run_policy`` -- every (video, threshold) job
-    batched into shared launches -- must make the decisions of the reference's one-job-at-a-time loop
-    (city_sender.py:495-607, restated in oracle/pipeline.py::run_clip on the CPU oracle's ELIC + score network + DDPM
-    sampler) when both draw the same injected noise: same transmit masks, same key-frame bit counts, frames within the
-    fp32 sampler tolerance.  Thresholds are picked from the oracle's own PSNR trace, away from every value the rule
-    compared against, so a 1e-4 difference between the two implementations cannot flip a decision."""
+def _policy_sweep_against_the_oracle(kind):
+    """``policy.run_policy`` -- every (video, threshold) job batched into shared launches -- against the reference's
+    one-job-at-a-time loop (city_sender.py:495-607, restated in oracle/pipeline.py::run_clip on the CPU oracle's ELIC + score
+    network + DDPM sampler) drawing the same injected noise.  ``kind``: "psnr" (decide_5to5) or "lpips" (decide_5to5_lpips with
+    LPIPS-AlexNet: HIP ``LpipsAlex`` in the batched loop, oracle/lpips.py in the oracle loop, same seeded stand-in weights)."""
     import evc_amd  # noqa: F401
     from evc_amd import policy as P, sampler as S, synthetic
     from evc_amd.config import default_config
@@ -166,6 +164,15 @@ def test_policy_sweep_against_the_oracle_sender_loop():
     p_net = ON.seeded_params(d_net, 9)
     p_elic = synthetic.elic_state_dict(3)
     clips = synthetic.make_clips(2, seed=0, frames=frames, size=size).astype(np.float64) / 255.0
+    lp = kind == "lpips"
+    distance, metric = None, P.PsnrMetric()
+    if lp:
+        from evc_amd.lpips import LpipsAlex
+        from oracle import lpips as OL
+        sd = OL.seeded_state_dict(8)
+        distance = lambda a, b: float(OL.distance(sd, a[None].float(), b[None].float())[0])
+        hip_lpips = LpipsAlex(sd)
+        metric = P.CallableMetric(lambda a, b: hip_lpips(a, b), name="lpips-alex-hip")
 
     def noise(job, rnd_no, step, shape):            # pure function of (video, round, step): both loops call it
         vid = job[0] if isinstance(job, tuple) else job
@@ -174,31 +181,36 @@ def test_policy_sweep_against_the_oracle_sender_loop():
     def oracle_job(vid, thr, trace=None):
         fn = lambda tag, shape: noise(vid, tag[0], 0 if tag[1] == "init" else int(tag[1]) + 1, shape[1:]).reshape(shape)
         return OP.run_clip(p_net, d_net, p_elic, torch.from_numpy(clips[vid]), threshold=thr, subsample=subsample,
-                           noise_fn=fn, coder=NativeCoder, frames=frames, trace=trace)
-    # a threshold in the widest gap of the PSNR values the rule meets when everything is accepted
+                           noise_fn=fn, coder=NativeCoder, frames=frames, trace=trace, distance=distance)
+    # thresholds in the widest gaps of the values the rule meets when everything is accepted, away from every value the rule
+    # compared against, so a 1e-4 difference between the two implementations cannot flip a decision
+    accept_all, reject_all = (1e9, -1.0) if lp else (-100.0, 200.0)
+    vids = (0,) if lp else (0, 1)                  # the LPIPS variant re-checks the rule, not the batching: one video, two gaps
     tr = []
-    for vid in (0, 1):
-        oracle_job(vid, -100.0, tr)
+    for vid in vids:
+        oracle_job(vid, accept_all, tr)
     v = np.sort(np.asarray(tr))
     gaps = np.diff(v)
-    mids = [float(v[k] + gaps[k] / 2) for k in np.argsort(gaps)[-3:]]          # the three widest gaps
-    thresholds = [-100.0] + sorted(mids) + [200.0]
+    mids = [float(v[k] + gaps[k] / 2) for k in np.argsort(gaps)[-(2 if lp else 3):]]          # the widest gaps
+    # lenient -> strict, the order of the reference's sweep (it stops at the first threshold that costs >= 1 bit per pixel)
+    thresholds = [accept_all] + sorted(mids, reverse=lp) + [reject_all]
+    tie = (lambda t, thr: abs(t - thr) < 2e-3 * abs(thr)) if lp else (lambda t, thr: abs(t - thr) < 0.02)
     cfg = default_config(32, 32, size, subsample=subsample)
     net = ScoreNet(cfg, p_net)
     elic = ElicModel(p_elic)
     dec = ClipDecoder(net, elic, cfg, S.get_sampler("DDPM"))
     stats = {}
-    res = P.run_policy(dec, {3: elic}, {vid: torch.from_numpy(clips[vid]).float() for vid in (0, 1)}, [3], thresholds,
-                       P.PsnrMetric(), patch=64, frames=frames, max_batch=4, noise_source=noise, stats=stats)
+    res = P.run_policy(dec, {3: elic}, {vid: torch.from_numpy(clips[vid]).float() for vid in vids}, [3], thresholds,
+                       metric, patch=64, frames=frames, max_batch=4, noise_source=noise, stats=stats)
     assert sum(stats["launch_sizes"].values()) >= 2 and max(stats["launch_sizes"]) > 1      # jobs really shared launches
     seen_masks, compared, cut = set(), 0, 0
-    for vid in (0, 1):
+    for vid in vids:
         got = {r["thr"]: r for r in res[(vid, 3)]}
         for thr in thresholds:
             trace = []
             ref = oracle_job(vid, thr, trace)
-            if min(abs(t - thr) for t in trace) < 0.02:
-                continue                                    # a tie within 0.02 dB: not a fair comparison point
+            if any(tie(t, thr) for t in trace):
+                continue                                    # a tie (0.02 dB / 0.2 % of the distance): not a fair comparison point
             if ref["bpp"] >= 1.0:
                 assert thr not in got                       # the sweep is cut at 1 bit per pixel (city_sender.py:563-564)
                 cut += 1
@@ -216,4 +228,15 @@ def test_policy_sweep_against_the_oracle_sender_loop():
             compared += 1
     # both videos' all-accepting jobs were compared, and the sweep held rejecting thresholds too (other masks, or jobs the
     # 1-bit-per-pixel rule cut in BOTH implementations)
-    assert compared >= 2 and (len(seen_masks) >= 2 or cut >= 2), (compared, cut, seen_masks)
+    assert compared >= len(vids) and (len(seen_masks) >= 2 or cut >= len(vids)), (compared, cut, seen_masks)
+
+
+def test_policy_sweep_against_the_oracle_sender_loop():
+    """SURVEY.md 8f item 2 against an ORACLE (not against itself), PSNR rule: same transmit masks, same key-frame bit counts,
+    frames within the fp32 sampler tolerance."""
+    _policy_sweep_against_the_oracle("psnr")
+
+
+def test_lpips_policy_sweep_against_the_oracle_sender_loop():
+    """The same with the reference's default rule, decide_5to5_lpips (city_sender.py:376-406), on LPIPS-AlexNet."""
+    _policy_sweep_against_the_oracle("lpips")
