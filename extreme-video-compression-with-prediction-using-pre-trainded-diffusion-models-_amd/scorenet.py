@@ -104,7 +104,8 @@ def _pad16(c):
 
 
 class ScoreNet:
-    """HIP implementation of ``UNetMore_DDPM`` (eval mode, dropout 0, spade/cond_emb/noise_in_cond off)."""
+    """HIP implementation of ``UNetMore_DDPM`` (eval mode, dropout 0), incl. its cond_emb / noise_in_cond / gamma / cosine-schedule
+    options (ncsnpp_more.py:61,97-99,282-285,735-768)."""
 
     SPADE = False      # scorenet_spade.SpadeScoreNet: conditioning through SPADE act-norms (model.spade: true)
 
@@ -121,17 +122,34 @@ class ScoreNet:
         self.d = dims_from_config(config)
         self.type = getattr(config.model, "type", "v1")
         m = config.model
-        if bool(getattr(m, "spade", False)) != self.SPADE or getattr(m, "cond_emb", False) or \
-                getattr(m, "noise_in_cond", False) or getattr(m, "output_all_frames", False) or m.arch != "unetmore":
-            raise NotImplementedError("only arch=unetmore without cond_emb / noise_in_cond / output_all_frames is built: "
-                                      "the concat-conditioned network of configs/mine.yml (ScoreNet) and its SPADE "
-                                      "variant (SpadeScoreNet); 3-D / pseudo-3-D archs are not (SURVEY.md section 2)")
-        # schedule buffers exactly as ncsnpp_more.py:735-739 builds them (CPU float32; the samplers index them)
-        if getattr(m, "sigma_dist", "linear") != "linear":
-            raise NotImplementedError("sigma_dist != linear")
-        self.betas = torch.linspace(self.d.sigma_begin, self.d.sigma_end, self.d.num_classes)
-        self.alphas = torch.cumprod(1 - self.betas.flip(0), 0).flip(0)
-        self.alphas_prev = torch.cat([self.alphas[1:], torch.tensor([1.0]).to(self.alphas)])
+        if bool(getattr(m, "spade", False)) != self.SPADE or getattr(m, "output_all_frames", False) or m.arch != "unetmore":
+            raise NotImplementedError("only arch=unetmore without output_all_frames is built: the concat-conditioned network "
+                                      "of configs/mine.yml (ScoreNet) and its SPADE variant (SpadeScoreNet); 3-D / pseudo-3-D "
+                                      "archs are not (SURVEY.md section 2); output_all_frames fails in the reference itself "
+                                      "(ncsnpp_more.py:384-385 splits 15 channels into 6 + 15)")
+        # cond_emb: the time embedding is extended by an Embedding(2, ngf // 2) row chosen by cond_mask (ncsnpp_more.py:97-99,
+        # :282-285); noise_in_cond: the conditioning frames are noised to the step's level before every forward (:753-768)
+        self.cond_emb = bool(getattr(m, "cond_emb", False))
+        self.noise_in_cond = bool(getattr(m, "noise_in_cond", False))
+        if (self.cond_emb or self.noise_in_cond) and self.SPADE:
+            raise NotImplementedError("cond_emb / noise_in_cond are built for the concat-conditioned network only")
+        self.cond_noise_fn = None        # tests inject the draw of noise_in_cond here: fn(cond) -> raw noise tensor
+        self.cond_generator = None
+        # schedule buffers exactly as ncsnpp_more.py:735-743 builds them (CPU float32; the samplers index them)
+        dist = getattr(m, "sigma_dist", "linear")
+        if dist == "linear":
+            self.betas = torch.linspace(self.d.sigma_begin, self.d.sigma_end, self.d.num_classes)
+            self.alphas = torch.cumprod(1 - self.betas.flip(0), 0).flip(0)
+            self.alphas_prev = torch.cat([self.alphas[1:], torch.tensor([1.0]).to(self.alphas)])
+        elif dist == "cosine":           # models/__init__.py:29-33 (get_sigmas) + ncsnpp_more.py:740-743
+            T = self.d.num_classes
+            t = torch.linspace(T, 0, T + 1) / T
+            f = torch.cos((t + 0.008) / (1 + 0.008) * math.pi / 2) ** 2
+            self.alphas = f[:-1] / f[-1]
+            self.alphas_prev = torch.cat([self.alphas[1:], torch.tensor([1.0]).to(self.alphas)])
+            self.betas = 1 - self.alphas / self.alphas_prev
+        else:
+            raise NotImplementedError(f"sigma_dist {dist!r}: UNetMore_DDPM builds its buffers for 'linear' and 'cosine' only")
         self.gamma = bool(getattr(m, "gamma", False))
         if self.gamma:       # Gamma-noise schedule buffers, ncsnpp_more.py:744-749 (read by the samplers' gamma=True branch)
             self.theta_0 = 0.001
@@ -186,8 +204,11 @@ class ScoreNet:
         self.w = {}
         dense_w, dense_b = [], []
         off = 0
+        if self.cond_emb:                # modules[2] = Embedding(2, ngf // 2): every later state-dict index is one higher
+            self.cond_table = self._dev(g(pre + "2.weight"))
+            assert tuple(self.cond_table.shape) == (2, self.d.ngf // 2), tuple(self.cond_table.shape)
         for i, m in enumerate(self.program):
-            n = pre + str(i)
+            n = pre + str(i + (1 if self.cond_emb and i >= 2 else 0))
             k = m["kind"]
             if k == "linear":
                 w = g(n + ".weight")
@@ -248,16 +269,25 @@ class ScoreNet:
         emb = torch.tensor(labels, dtype=torch.float32)[:, None] * emb[None, :]
         return torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
 
-    def prepare_labels(self, labels):
-        """Evaluate temb MLP + every AdaGN Dense_0 for the labels not in the table yet (one batched pass)."""
-        new = [float(v) for v in dict.fromkeys(float(x) for x in labels) if float(v) not in self._rows]
+    def _key(self, label, mask=1):
+        """Key of an AdaGN-table row: the label, and with cond_emb the conditioning flag that picks the embedding row."""
+        return (float(label), int(mask)) if self.cond_emb else float(label)
+
+    def prepare_labels(self, labels, masks=None):
+        """Evaluate temb MLP + every AdaGN Dense_0 for the labels not in the table yet (one batched pass).  ``masks``: with
+        cond_emb, the cond_mask value of each label (default 1, as the reference does for cond_mask=None)."""
+        masks = [1] * len(labels) if masks is None else masks
+        new = [k for k in dict.fromkeys(self._key(x, mk) for x, mk in zip(labels, masks)) if k not in self._rows]
         if not new:
             return
         R = len(new)
-        e = self._embedding(new).to(self.device).reshape(1, 1, R, self.d.ngf).contiguous()
+        e = self._embedding([k[0] if self.cond_emb else k for k in new]).to(self.device).reshape(1, 1, R, self.d.ngf).contiguous()
         w0, w1 = self.w[0], self.w[1]
         t = L.conv2d_nhwc(e, w0["w"], w0["co"], 1, 1, bias=w0["b"])                       # Linear(ngf -> 4ngf)
         t = L.conv2d_nhwc(t, w1["w"], w1["co"], 1, 1, bias=w1["b"], act_in=L.ACT_SILU)    # act -> Linear
+        if self.cond_emb:                # temb = cat([temb, Embedding(cond_mask)]) (ncsnpp_more.py:282-285); rows are label-major
+            emb = self.cond_table[torch.tensor([k[1] for k in new], device=self.device)]
+            t = torch.cat([t.reshape(R, -1), emb], 1).reshape(1, 1, R, -1).contiguous()
         rows = L.conv2d_nhwc(t, self.dense_w, self.ss_total, 1, 1, bias=self.dense_b, act_in=L.ACT_SILU)
         base = self._n_rows
         if base + R > self._table.shape[0]:
@@ -495,21 +525,57 @@ class ScoreNet:
             out = self.forward_rows(sx, srows, scond)
         return dict(graph=graph, x=sx, rows=srows, cond=scond, out=out)
 
+    def _noised_cond(self, cond, vals):
+        """noise_in_cond (ncsnpp_more.py:755-768): cond <- sqrt(a) cond + sqrt(1 - a) z with a = alphas[label] per sample,
+        z Gaussian -- or, on a gamma model, a standardised Gamma(k_cum[label], rate 1/theta_t[label]) draw -- fresh on every
+        call, as the reference draws it in every forward.  ``cond_noise_fn`` (tests) supplies the raw draw."""
+        if not self.noise_in_cond or cond is None:
+            return cond
+        if any(v != int(v) or v < 0 for v in vals):
+            raise IndexError("noise_in_cond indexes the schedule with the labels (alphas[labels]): integer labels only")
+        raw = None if self.cond_noise_fn is None else self.cond_noise_fn(cond).to(self.device, torch.float32).contiguous()
+        out = torch.empty_like(cond)
+        start = 0
+        while start < len(vals):                     # runs of equal labels (the samplers: one run)
+            end = start
+            while end < len(vals) and vals[end] == vals[start]:
+                end += 1
+            i = int(vals[start])
+            a = self.alphas[i]
+            c = cond[start:end].contiguous()
+            if self.gamma:
+                from .sampler import _gamma_noise
+                z = _gamma_noise(c, self.k_cum[i], self.theta_t[i], a, raw=None if raw is None else raw[start:end],
+                                 generator=self.cond_generator)
+            elif raw is not None:
+                z = raw[start:end].contiguous()
+            else:
+                z = torch.randn(c.shape, device=self.device, dtype=torch.float32, generator=self.cond_generator)
+            out[start:end] = L.lincomb4([c, z], [float(a.sqrt()), float((1 - a).sqrt())])
+            start = end
+        return out
+
     def forward_label(self, x, label, cond=None):
         """All samples share one label (what every sampler does): no device->host sync."""
         self.prepare_labels([label])
-        rows = self._row_tensor([self._rows[float(label)]] * x.shape[0])
+        rows = self._row_tensor([self._rows[self._key(label)]] * x.shape[0])
+        if self.noise_in_cond and cond is not None:
+            cond = self._noised_cond(cond.to(self.device, torch.float32).contiguous(), [float(label)] * x.shape[0])
         return self._forward(x, rows, cond)
 
     def __call__(self, x, labels, cond=None, cond_mask=None):
-        """Reference call shape: ``scorenet(x, labels, cond=cond)`` (models/__init__.py:265,285)."""
+        """Reference call shape: ``scorenet(x, labels, cond=cond)`` (models/__init__.py:265,285); ``cond_mask`` (one flag per
+        sample, default ones) only matters with cond_emb."""
         vals = [float(v) for v in (labels.detach().cpu().tolist() if torch.is_tensor(labels) else labels)]
         assert len(vals) == x.shape[0]
-        self.prepare_labels(vals)
-        rows = self._row_tensor([self._rows[v] for v in vals])
+        masks = None
+        if self.cond_emb and cond_mask is not None:
+            masks = [int(v) for v in (cond_mask.detach().cpu().tolist() if torch.is_tensor(cond_mask) else cond_mask)]
+        self.prepare_labels(vals, masks)
+        rows = self._row_tensor([self._rows[self._key(v, 1 if masks is None else masks[j])] for j, v in enumerate(vals)])
         x = x.to(self.device, torch.float32).contiguous()
         cond = None if cond is None else cond.to(self.device, torch.float32).contiguous()
-        return self._forward(x, rows, cond)
+        return self._forward(x, rows, self._noised_cond(cond, vals))
 
     forward = __call__
 

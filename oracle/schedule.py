@@ -16,6 +16,17 @@ def base_schedule(sigma_begin=0.02, sigma_end=1e-4, num_classes=1000):
     return betas, alphas, alphas_prev
 
 
+def cosine_schedule(num_classes=1000):
+    """sigma_dist 'cosine': get_sigmas (models/__init__.py:29-33) are the alphas, betas derived (ncsnpp_more.py:740-743)."""
+    import numpy as np
+    T = num_classes
+    t = torch.linspace(T, 0, T + 1) / T
+    f = torch.cos((t + 0.008) / (1 + 0.008) * np.pi / 2) ** 2
+    alphas = f[:-1] / f[-1]
+    alphas_prev = torch.cat([alphas[1:], torch.tensor([1.0]).to(alphas)])
+    return 1 - alphas / alphas_prev, alphas, alphas_prev
+
+
 def subsample(alphas, alphas_prev, betas, subsample_steps):
     """models/__init__.py:231-239: returns (steps, alphas, alphas_prev, betas) after subsampling."""
     steps = torch.arange(len(betas))

@@ -30,6 +30,7 @@ class Dims:
     channels: int = 3
     num_frames: int = 5
     num_frames_cond: int = 2
+    cond_emb: bool = False          # config.model.cond_emb: Embedding(2, ngf // 2) appended to the time embedding
 
 
 def num_groups(ch):
@@ -155,17 +156,28 @@ def _attn(x, p, pre, head_ch):
 
 
 @torch.no_grad()
-def forward(p, d: Dims, x, labels, cond=None, prefix="unet.all_modules.", taps=None):
+def noise_cond(cond, labels, alphas, z):
+    """UNetMore_DDPM.forward with noise_in_cond (ncsnpp_more.py:755-768): the conditioning frames noised to each sample's
+    level, ``z`` the draw (Gaussian; a standardised Gamma draw on gamma models)."""
+    a = alphas[labels.long()].reshape(cond.shape[0], *([1] * len(cond.shape[1:])))
+    return a.sqrt() * cond + (1 - a).sqrt() * z
+
+
+def forward(p, d: Dims, x, labels, cond=None, prefix="unet.all_modules.", taps=None, cond_mask=None):
     """UNetMore_DDPM.forward -> NCSNpp.forward (ncsnpp_more.py:753-770, :251-392).
 
-    ``taps``: optional dict; if given, the output of every module index is stored in it."""
+    ``taps``: optional dict; if given, the output of every module index is stored in it (program indices)."""
     mods = program(d)
-    name = lambda i: prefix + str(i)
+    name = lambda i: prefix + str(_sd_index(d, i))
     if cond is not None:
         x = torch.cat([x, cond], dim=1)
     temb = timestep_embedding(labels, d.ngf)
     temb = F.linear(temb, p[name(0) + ".weight"], p[name(0) + ".bias"])
     temb = F.linear(F.silu(temb), p[name(1) + ".weight"], p[name(1) + ".bias"])
+    if d.cond_emb:                                                                   # :282-285
+        if cond_mask is None:
+            cond_mask = torch.ones(x.shape[0], dtype=torch.int32)
+        temb = torch.cat([temb, F.embedding(cond_mask.long(), p[prefix + "2.weight"])], dim=1)
     i = 2
     x = x.contiguous().float()
 
@@ -216,20 +228,28 @@ def forward(p, d: Dims, x, labels, cond=None, prefix="unet.all_modules.", taps=N
     return h
 
 
+def _sd_index(d, i):
+    """State-dict index of program entry ``i``: with cond_emb the Embedding sits at modules[2] and shifts the rest."""
+    return i + (1 if d.cond_emb and i >= 2 else 0)
+
+
 def param_shapes(d: Dims, prefix="unet.all_modules."):
     """Ordered (name, shape) list in reference ``state_dict()`` order for the network parameters."""
     out = []
+    td = 4 * d.ngf + (d.ngf // 2 if d.cond_emb else 0)           # temb_dim (ncsnpp_more.py:95-99)
     for i, m in enumerate(program(d)):
-        n = prefix + str(i)
+        n = prefix + str(_sd_index(d, i))
+        if i == 2 and d.cond_emb:
+            out += [(prefix + "2.weight", (2, d.ngf // 2))]      # torch.nn.Embedding(2, nf // 2), modules[2]
         if m["kind"] == "linear":
             out += [(n + ".weight", (m["cout"], m["cin"])), (n + ".bias", (m["cout"],))]
         elif m["kind"] == "conv3":
             out += [(n + ".weight", (m["cout"], m["cin"], 3, 3)), (n + ".bias", (m["cout"],))]
         elif m["kind"] == "res":
             ci, co = m["cin"], m["cout"]
-            out += [(n + ".actnorm0.Dense_0.weight", (2 * ci, 4 * d.ngf)), (n + ".actnorm0.Dense_0.bias", (2 * ci,)),
+            out += [(n + ".actnorm0.Dense_0.weight", (2 * ci, td)), (n + ".actnorm0.Dense_0.bias", (2 * ci,)),
                     (n + ".Conv_0.weight", (co, ci, 3, 3)), (n + ".Conv_0.bias", (co,)),
-                    (n + ".actnorm1.Dense_0.weight", (2 * co, 4 * d.ngf)), (n + ".actnorm1.Dense_0.bias", (2 * co,)),
+                    (n + ".actnorm1.Dense_0.weight", (2 * co, td)), (n + ".actnorm1.Dense_0.bias", (2 * co,)),
                     (n + ".Conv_1.weight", (co, co, 3, 3)), (n + ".Conv_1.bias", (co,))]
             if ci != co or m["up"] or m["down"]:
                 out += [(n + ".Conv_2.weight", (co, ci, 1, 1)), (n + ".Conv_2.bias", (co,))]

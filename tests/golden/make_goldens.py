@@ -37,9 +37,10 @@ def d2n(d):
     return ns
 
 
-def ref_config(ngf, head, image_size, gamma=False):
+def ref_config(ngf, head, image_size, gamma=False, **model_flags):
     cfg = yaml.safe_load(open(os.path.join(REF, "configs/mine.yml")))
     cfg["model"]["gamma"] = gamma
+    cfg["model"].update(model_flags)
     cfg["model"]["ngf"] = ngf
     cfg["model"]["n_head_channels"] = head
     cfg["data"]["image_size"] = image_size
@@ -48,10 +49,10 @@ def ref_config(ngf, head, image_size, gamma=False):
     return config
 
 
-def ref_net(ngf, head, image_size, seed, gamma=False):
+def ref_net(ngf, head, image_size, seed, gamma=False, **model_flags):
     from models.better.ncsnpp_more import UNetMore_DDPM
-    net = UNetMore_DDPM(ref_config(ngf, head, image_size, gamma)).eval()
-    d = Dims(ngf=ngf, n_head_channels=head, image_size=image_size)
+    net = UNetMore_DDPM(ref_config(ngf, head, image_size, gamma, **model_flags)).eval()
+    d = Dims(ngf=ngf, n_head_channels=head, image_size=image_size, cond_emb=bool(model_flags.get("cond_emb", False)))
     p = seeded_params(d, seed)
     own = dict(net.named_parameters())
     assert set(own) == set(p), (sorted(set(own) ^ set(p))[:8])
@@ -245,6 +246,39 @@ def gamma_raw(count, k, theta, shape):
     return kk * th + 0.5 * rnd(500 + count, *shape)
 
 
+def gen_model_options():
+    """Options of UNetMore_DDPM no shipped config sets (reduced net, ncsnpp_more.py:61,97-99,282-285,735-768): ``cond_emb`` (an
+    Embedding(2, ngf/2) row chosen by cond_mask extends the time embedding), ``noise_in_cond`` (the conditioning frames are
+    noised to the step's level inside forward; the draw is injected), ``sigma_dist: cosine`` (schedule buffers + a DDPM run)."""
+    from models import ddpm_sampler
+    x, cond = rnd(61, 2, 15, 32, 32), rnd(62, 2, 6, 32, 32)
+    out = {}
+    with torch.no_grad():
+        net, _ = ref_net(32, 32, 32, 43, cond_emb=True)
+        out["cond_emb_default"] = net(x, torch.tensor([500, 7]), cond=cond)
+        out["cond_emb_mask10"] = net(x, torch.tensor([500, 7]), cond=cond, cond_mask=torch.tensor([1, 0], dtype=torch.int32))
+        net, _ = ref_net(32, 32, 32, 44, noise_in_cond=True)
+        z = rnd(63, 2, 6, 32, 32)
+        orig = torch.randn_like
+        torch.randn_like = lambda t, **k: z
+        try:
+            out["noise_in_cond"] = net(x, torch.tensor([500, 7]), cond=cond)
+        finally:
+            torch.randn_like = orig
+        net, _ = ref_net(32, 32, 32, 45, sigma_dist="cosine")
+        out.update(cos_betas=net.betas, cos_alphas=net.alphas, cos_alphas_prev=net.alphas_prev)
+        noises = [rnd(640 + i, 2, 15, 32, 32) for i in range(12)]
+        it = iter(noises)
+        torch.randn_like = lambda t, **k: next(it)
+        try:
+            out["cos_ddpm"] = ddpm_sampler(x.clone(), net, cond=cond, denoise=True, clip_before=True, final_only=True, log=False,
+                                           subsample_steps=10)
+        finally:
+            torch.randn_like = orig
+        out["cos_noises_used"] = np.asarray(12 - len(list(it)))
+    save("model_options", **out)
+
+
 def gen_forward_full():
     torch.set_num_threads(8)
     net, d = ref_net(192, 192, 128, 1234)
@@ -379,7 +413,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     gens = dict(schedule=gen_schedule, fir=gen_fir, blocks=gen_blocks, forward_reduced=gen_forward_reduced,
-                samplers=gen_samplers, sampler_options=gen_sampler_options, sampler_gamma=gen_sampler_gamma,
+                samplers=gen_samplers, sampler_options=gen_sampler_options, sampler_gamma=gen_sampler_gamma, model_options=gen_model_options,
                 forward_full=gen_forward_full, forward_full_b9=gen_forward_full_b9,
                 traj_full=gen_traj_full, traj_fpndm_full=gen_traj_fpndm_full, unet_ddpm=gen_unet_ddpm, forward_spade=gen_forward_spade)
     for name, fn in gens.items():

@@ -319,6 +319,56 @@ def test_sampler_gamma_noise_against_reference_goldens():
     assert abs(float(z.mean())) < 0.02 and abs(float(z.var()) - 1.0) < 0.1
 
 
+def test_model_options_cond_emb_noise_in_cond_and_cosine_schedule():
+    """UNetMore_DDPM options no shipped config sets, against the reference (ncsnpp_more.py:61,97-99,282-285,735-768):
+    ``cond_emb`` (default mask and an explicit per-sample one), ``noise_in_cond`` (injected draw; every forward re-noises the
+    conditioning frames), ``sigma_dist: cosine`` (buffers and a DDPM run); ``output_all_frames`` -- which fails in the reference
+    itself -- stays NotImplementedError."""
+    import evc_amd  # noqa: F401
+    from evc_amd import sampler
+    from evc_amd.scorenet import ScoreNet
+    from oracle.scorenet import Dims, seeded_params
+    g = golden("model_options")
+    x, cond = rnd(61, 2, 15, 32, 32).cuda(), rnd(62, 2, 6, 32, 32).cuda()
+    labels = torch.tensor([500, 7])
+
+    def build_with(seed, **flags):
+        cfg = make_config(32, 32, 32)
+        for k, v in flags.items():
+            setattr(cfg.model, k, v)
+        d = Dims(ngf=32, n_head_channels=32, image_size=32, cond_emb=bool(flags.get("cond_emb", False)))
+        return ScoreNet(cfg, seeded_params(d, seed))
+    net = build_with(43, cond_emb=True)
+    assert rel(net(x, labels, cond=cond), g["cond_emb_default"]) < 1e-4
+    assert rel(net(x, labels, cond=cond, cond_mask=torch.tensor([1, 0], dtype=torch.int32)), g["cond_emb_mask10"]) < 1e-4
+    assert rel(net.forward_label(x[:1], 500, cond[:1]), g["cond_emb_default"][:1]) < 1e-4       # the samplers' entry point
+    net = build_with(44, noise_in_cond=True)
+    calls = []
+    net.cond_noise_fn = lambda c: (calls.append(tuple(c.shape)), rnd(63, 2, 6, 32, 32))[1]
+    assert rel(net(x, labels, cond=cond), g["noise_in_cond"]) < 1e-4
+    sampler.ddpm_sampler(x, net, cond=cond, subsample_steps=2, denoise=True, final_only=True, noise_fn=lambda t, xx: torch.zeros_like(xx))
+    assert len(calls) == 1 + 3                                # one draw per forward: 2 steps + the denoise pass
+    net.cond_noise_fn = None
+    torch.manual_seed(3)
+    a = net(x, labels, cond=cond)
+    b = net(x, labels, cond=cond)
+    assert torch.isfinite(a).all() and not torch.equal(a, b)  # fresh noise on every call
+    with pytest.raises(IndexError):                           # alphas[labels] with a fractional label fails in the reference too
+        net(x, torch.tensor([-0.5, -0.5]), cond=cond)
+    net = build_with(45, sigma_dist="cosine")
+    for name in ("betas", "alphas", "alphas_prev"):
+        np.testing.assert_allclose(getattr(net, name).numpy(), g["cos_" + name], rtol=2e-6, atol=1e-9)
+        setattr(net, name, torch.from_numpy(g["cos_" + name].copy()))          # cos() differs by an ulp between hosts
+    it = iter([rnd(640 + i, 2, 15, 32, 32) for i in range(int(g["cos_noises_used"]))])
+    out = sampler.ddpm_sampler(x, net, cond=cond, subsample_steps=10, denoise=True, clip_before=True, final_only=True,
+                               noise_fn=lambda tag, xx: next(it))
+    assert out.shape == g["cos_ddpm"].shape and rel(out, g["cos_ddpm"]) < 5e-4
+    with pytest.raises(NotImplementedError):
+        build_with(43, output_all_frames=True)
+    with pytest.raises(NotImplementedError):
+        build_with(43, sigma_dist="geometric")
+
+
 def test_sampler_label_sequences_match_reference():
     import evc_amd  # noqa: F401
     from evc_amd import sampler

@@ -143,6 +143,34 @@ def test_sampler_gamma_noise_against_reference_goldens():
         first += n
 
 
+def test_model_options_cond_emb_noise_in_cond_and_cosine_schedule():
+    """UNetMore_DDPM options no shipped config sets, against the reference (ncsnpp_more.py:61,97-99,282-285,735-768): the
+    cond_emb embedding row appended to the time embedding (default mask and an explicit one), noise_in_cond with the injected
+    draw, the cosine schedule's buffers and a DDPM run on them."""
+    g = golden("model_options")
+    x, cond = rnd(61, 2, 15, 32, 32), rnd(62, 2, 6, 32, 32)
+    labels = torch.tensor([500, 7])
+    d = Dims(ngf=32, n_head_channels=32, image_size=32, cond_emb=True)
+    p = seeded_params(d, 43)
+    assert _rel(scorenet.forward(p, d, x, labels, cond=cond).numpy(), g["cond_emb_default"]) < 1e-4
+    out = scorenet.forward(p, d, x, labels, cond=cond, cond_mask=torch.tensor([1, 0], dtype=torch.int32))
+    assert _rel(out.numpy(), g["cond_emb_mask10"]) < 1e-4
+    assert _rel(g["cond_emb_mask10"][0], g["cond_emb_default"][0]) < 1e-6 and _rel(g["cond_emb_mask10"][1], g["cond_emb_default"][1]) > 1e-3
+    d, p = _net(44)
+    sched = schedule.base_schedule()
+    noised = scorenet.noise_cond(cond, labels, sched[1], rnd(63, 2, 6, 32, 32))
+    assert _rel(scorenet.forward(p, d, x, labels, cond=noised).numpy(), g["noise_in_cond"]) < 1e-4
+    cos = schedule.cosine_schedule()
+    for name, v in zip(("cos_betas", "cos_alphas", "cos_alphas_prev"), cos):
+        np.testing.assert_allclose(v.numpy(), g[name], rtol=2e-6, atol=1e-9)      # cos() differs by an ulp between hosts
+    cos = tuple(torch.from_numpy(g[k].copy()) for k in ("cos_betas", "cos_alphas", "cos_alphas_prev"))
+    d, p = _net(45)
+    it = iter([rnd(640 + i, 2, 15, 32, 32) for i in range(int(g["cos_noises_used"]))])
+    out = samplers.ddpm(x.clone(), lambda xx, t: scorenet.forward(p, d, xx, t, cond=cond), cos, subsample_steps=10,
+                        noise_fn=lambda tag, xx: next(it))
+    assert _rel(out.numpy(), g["cos_ddpm"]) < 1e-4
+
+
 def test_label_sequences():
     g = golden("label_sequences")
     sched = schedule.base_schedule()
