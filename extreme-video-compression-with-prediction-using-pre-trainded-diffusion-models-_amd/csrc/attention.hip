@@ -510,18 +510,41 @@ AttnPlan attention_plan_f16(int B, int heads, int N) {
     return p;
 }
 
+// attention_kernel<256, *> stages 2 x 32 x 260 floats = 65 KB: above the 64 KB a kernel gets without asking
+template <int D, int WAVES>
+int launch_f32(dim3 grid, size_t lds, hipStream_t st, const float* q, const float* k, const float* v, int ld, float* out, int ld_out,
+               int N, float scale, int kparts, int tiles_per_part, float* part_o, float* part_ml) {
+    if (lds > 64 * 1024) {
+        static unsigned long long done = 0;                       // one bit per device id, set after the call succeeded
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return EVC_ELAUNCH;
+        const unsigned long long bit = 1ULL << (dev & 63);
+        if (!(__atomic_load_n(&done, __ATOMIC_ACQUIRE) & bit)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<D, WAVES>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return EVC_ELAUNCH;
+            __atomic_fetch_or(&done, bit, __ATOMIC_RELEASE);
+        }
+    }
+    hipLaunchKernelGGL((attention_kernel<D, WAVES>), grid, dim3(64 * WAVES), lds, st, q, k, v, ld, out, ld_out, N, scale, kparts,
+                       tiles_per_part, part_o, part_ml);
+    return EVC_OK;
+}
+
 template <int D>
 int launch(const float* q, const float* k, const float* v, int ld, float* out, int ld_out, int B, int heads, int N,
            float scale, float* ws, const unsigned* bounds, hipStream_t st) {
     const size_t lds = (size_t)2 * 32 * (D + 4) * sizeof(float);
-    const AttnPlan pl = (bounds && ws && N >= 128) ? attention_plan_f16(B, heads, N) : attention_plan(B, heads, N, ws != nullptr);
+    // head widths above 192 stay on the f32 kernel: the fp16 kernel keeps Q (both planes) and O in registers, D/2 + D/2 of them
+    constexpr bool F16_OK = D <= 192;
+    const bool use_f16 = F16_OK && bounds && N >= 128;
+    const AttnPlan pl = (use_f16 && ws) ? attention_plan_f16(B, heads, N) : attention_plan(B, heads, N, ws != nullptr);
     const int waves = pl.waves;
     float* part_o = ws;
     float* part_ml = ws ? ws + (size_t)pl.kparts * B * N * heads * D : nullptr;
     dim3 grid(((N + 32 * waves - 1) / (32 * waves)) * pl.kparts, heads, B);
     // tiny key sets (N < 128: the 8x8 level) stay on the f32 kernel: with two key tiles there is nothing to amortise the
     // fp16 conversion of K / V over (measured B=9, 8x8: 26 us f32 vs 39 us fp16 split; 16x16: 81 vs 29; 32x32: 260 vs 155)
-    if (bounds && N >= 128) {
+    if constexpr (F16_OK) if (use_f16) {
         const size_t lds16 = (size_t)2 * 32 * (2 * D + 16) + (size_t)2 * D * 80;
         if (waves == 4)
             hipLaunchKernelGGL((attention_f16_kernel<D, 4>), grid, dim3(256), lds16, st, q, k, v, ld, out, ld_out, N, scale,
@@ -532,15 +555,13 @@ int launch(const float* q, const float* k, const float* v, int ld, float* out, i
         else
             hipLaunchKernelGGL((attention_f16_kernel<D, 1>), grid, dim3(64), lds16, st, q, k, v, ld, out, ld_out, N, scale,
                                bounds, pl.kparts, pl.tiles_per_part, part_o, part_ml);
-    } else if (waves == 4)
-        hipLaunchKernelGGL((attention_kernel<D, 4>), grid, dim3(256), lds, st, q, k, v, ld, out, ld_out, N, scale,
-                           pl.kparts, pl.tiles_per_part, part_o, part_ml);
-    else if (waves == 2)
-        hipLaunchKernelGGL((attention_kernel<D, 2>), grid, dim3(128), lds, st, q, k, v, ld, out, ld_out, N, scale,
-                           pl.kparts, pl.tiles_per_part, part_o, part_ml);
-    else
-        hipLaunchKernelGGL((attention_kernel<D, 1>), grid, dim3(64), lds, st, q, k, v, ld, out, ld_out, N, scale,
-                           pl.kparts, pl.tiles_per_part, part_o, part_ml);
+    }
+    if (!use_f16) {
+        const int rc = waves == 4 ? launch_f32<D, 4>(grid, lds, st, q, k, v, ld, out, ld_out, N, scale, pl.kparts, pl.tiles_per_part, part_o, part_ml)
+                     : waves == 2 ? launch_f32<D, 2>(grid, lds, st, q, k, v, ld, out, ld_out, N, scale, pl.kparts, pl.tiles_per_part, part_o, part_ml)
+                                  : launch_f32<D, 1>(grid, lds, st, q, k, v, ld, out, ld_out, N, scale, pl.kparts, pl.tiles_per_part, part_o, part_ml);
+        if (rc != EVC_OK) return rc;
+    }
     if (hipGetLastError() != hipSuccess) return EVC_ELAUNCH;
     if (pl.kparts > 1) {
         const size_t total = (size_t)B * N * heads * (D / 4);
@@ -562,7 +583,9 @@ static int attention_dispatch(const float* q, const float* k, const float* v, in
     if ((ld_qkv & 3) || (ld_out & 3)) return EVC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     switch (D) {
+        case 256: return launch<256>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, ws, bounds, st);
         case 192: return launch<192>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, ws, bounds, st);
+        case 128: return launch<128>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, ws, bounds, st);
         case 64: return launch<64>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, ws, bounds, st);
         case 32: return launch<32>(q, k, v, ld_qkv, out, ld_out, B, heads, N, scale, ws, bounds, st);
         default: return EVC_EUNSUPPORTED;

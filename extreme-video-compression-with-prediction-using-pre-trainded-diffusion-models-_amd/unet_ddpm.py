@@ -27,7 +27,7 @@ import torch
 from . import lib as L
 from .scorenet import _Act, _pad16
 
-ATTENTION_WIDTHS = (32, 64, 192)      # head widths attention_dispatch (csrc/attention.hip) instantiates
+ATTENTION_WIDTHS = (32, 64, 128, 192, 256)      # head widths attention_dispatch (csrc/attention.hip) instantiates
 
 BOX2 = np.ones((2, 2), dtype=np.float32)
 ONE = np.ones((1, 1), dtype=np.float32)
@@ -78,7 +78,7 @@ class UNetDDPM:
         if bad:
             raise NotImplementedError(
                 f"UNetDDPM with ngf={m_.ngf} (mode {mode_!r}) attends in one head of width "
-                f"{bad}; the HIP attention kernels exist for widths {list(ATTENTION_WIDTHS)} only, i.e. ngf in (16, 32, 96) "
+                f"{bad}; the HIP attention kernels exist for widths {list(ATTENTION_WIDTHS)} only, i.e. ngf in (16, 32, 64, 96, 128) "
                 f"with mode 'deep'.  (The network the reference CLI builds, arch 'unetmore', has 192-wide heads and is "
                 f"fully supported.)")
         L.hip_lib()

@@ -216,7 +216,8 @@ int evc_conv2d_nhwc_profiled_f32(const evc_conv_args* a, float* ws, void* stream
 
 /* ---- multi-head spatial self-attention ------------------------------------------------------
  * out[b][n][h*D + d] = sum_m softmax_m(q[b][n][h].k[b][m][h] * scale) * v[b][m][h][d]
- * q, k, v: [B][N][ld_*] token-major with head h at channel offset h*D; D in {32, 64, 192}.
+ * q, k, v: [B][N][ld_*] token-major with head h at channel offset h*D; D in {32, 64, 128, 192, 256}
+ * (256: always the f32 kernel -- the fp16-split kernel keeps Q and O in registers, D/2 + D/2 of them).
  * Replaces the two einsums + softmax of AttnBlockpp.forward (models/better/layerspp.py:241-246). */
 int evc_attention_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out, int B,
                       int heads, int N, int D, float scale, void* stream);

@@ -377,6 +377,15 @@ def gen_unet_ddpm():
             finally:
                 torch.randn_like = orig
             out["alphas"] = net.alphas
+    # the same network at ngf 64: its attention runs in one 128-wide head (a second kernel instantiation on the GPU side)
+    cfg = ref_config(64, 64, 32)
+    cfg.model.time_conditional = True
+    net = UNet_DDPM(cfg).eval()
+    p = OU.seeded_params(OU.Dims(ngf=64, time_conditional=True), 64)
+    missing, unexpected = net.load_state_dict(p, strict=False)
+    assert not unexpected and all(not m.startswith("unet.") for m in missing), missing
+    with torch.no_grad():
+        out["out_ngf64_t500"] = net(rnd(62, 1, 15, 32, 32), torch.tensor([500]), cond=rnd(63, 1, 6, 32, 32))
     save("unet_ddpm", **out)
 
 

@@ -524,7 +524,8 @@ def attn_f16(request):
     return request.param
 
 
-@pytest.mark.parametrize("B,heads,N,D", [(2, 2, 1024, 192), (1, 4, 64, 192), (2, 3, 256, 192), (2, 2, 96, 32), (1, 1, 64, 64)])
+@pytest.mark.parametrize("B,heads,N,D", [(2, 2, 1024, 192), (1, 4, 64, 192), (2, 3, 256, 192), (2, 2, 96, 32), (1, 1, 64, 64),
+                                         (2, 1, 256, 128), (1, 2, 64, 128), (2, 1, 256, 256), (1, 1, 100, 256)])
 def test_attention(L, attn_f16, B, heads, N, D):
     C = heads * D
     qkv = rnd(40, B, N, 3 * C).cuda()

@@ -493,6 +493,11 @@ def test_alt_model_unet_ddpm_against_reference_goldens():
             out = sampler.ddpm_sampler(x, net, cond=cond, subsample_steps=4, denoise=True, clip_before=True,
                                        final_only=True, noise_fn=lambda i, xx: noises[i])
             assert out.shape == g["ddpm_tc"].shape and rel(out, g["ddpm_tc"]) < 5e-4
+    cfg = make_config(64, 64, 32)                     # ngf 64: one 128-wide attention head (evc_attention_*, D = 128)
+    cfg.model.time_conditional = True
+    net = UNetDDPM(cfg, OU.seeded_params(OU.Dims(ngf=64, time_conditional=True), 64))
+    out = net(rnd(62, 1, 15, 32, 32).cuda(), torch.tensor([500]), cond=rnd(63, 1, 6, 32, 32).cuda())
+    assert rel(out, g["out_ngf64_t500"]) < 1e-4
 
 
 def build_spade(ngf, head, image_size, seed, spade_dim):

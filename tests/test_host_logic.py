@@ -84,17 +84,17 @@ def test_compute_path_fails_loudly_without_gpu():
 
 def test_alt_model_refuses_head_widths_without_an_attention_kernel():
     """UNetDDPM attends in ONE head of width 2*ngf (and the deepest width in the middle block); the HIP attention kernels
-    exist for widths 32 / 64 / 192.  Every other size -- including mine.yml's ngf = 192 with model.arch: unet -- must be
+    exist for widths 32 / 64 / 128 / 192 / 256.  Every other size -- including mine.yml's ngf = 192 with model.arch: unet -- must be
     refused by the constructor with a message that names the supported sizes, not fail inside the first forward."""
     import evc_amd  # noqa: F401
     from evc_amd.config import default_config
     from evc_amd.unet_ddpm import ATTENTION_WIDTHS, UNetDDPM, build_program
-    for ngf, ok in ((16, True), (32, True), (96, True), (64, False), (128, False), (192, False)):
+    for ngf, ok in ((16, True), (32, True), (64, True), (96, True), (128, True), (48, False), (192, False)):
         widths = {m["ch"] for _, _, m in build_program(ngf, "deep", 21) if m["kind"] == "attn"}
         assert all(w in ATTENTION_WIDTHS for w in widths) == ok, (ngf, widths)
     cfg = default_config(192, 192, 128)
     cfg.model.arch = "unet"
-    with pytest.raises(NotImplementedError, match="ngf in \\(16, 32, 96\\)"):
+    with pytest.raises(NotImplementedError, match="ngf in \\(16, 32, 64, 96, 128\\)"):
         UNetDDPM(cfg, {})
 
 

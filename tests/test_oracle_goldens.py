@@ -226,6 +226,9 @@ def test_unet_ddpm_oracle_matches_reference_goldens():
     traj = OS.ddpm(x.clone(), lambda xx, t: OU.forward(p, d, xx, t, cond=cond), OSch.base_schedule(), subsample_steps=4,
                    noise_fn=lambda i, xx: noises[i])
     assert float(np.abs(traj.numpy() - g["ddpm_tc"]).max() / np.abs(g["ddpm_tc"]).max()) < 1e-4
+    d = OU.Dims(ngf=64, time_conditional=True)                          # 128-wide attention head
+    out = OU.forward(OU.seeded_params(d, 64), d, rnd(62, 1, 15, 32, 32), torch.tensor([500]), cond=rnd(63, 1, 6, 32, 32))
+    assert float(np.abs(out.numpy() - g["out_ngf64_t500"]).max() / np.abs(g["out_ngf64_t500"]).max()) < 2e-5
 
 
 def test_spade_scorenet_oracle_matches_reference_goldens():
