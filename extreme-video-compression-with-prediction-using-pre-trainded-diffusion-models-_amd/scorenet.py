@@ -103,7 +103,69 @@ def _pad16(c):
     return (c + 15) // 16 * 16
 
 
-class ScoreNet:
+class DdpmWrapper:
+    """What ``UNetMore_DDPM.__init__`` / ``forward`` (ncsnpp_more.py:735-768) and ``UNet_DDPM`` (models/unet.py:337-372) do
+    around the network itself, shared by ScoreNet and UNetDDPM: the schedule buffers the samplers index (linear or cosine),
+    the Gamma-noise buffers, and ``noise_in_cond``."""
+
+    def _init_wrapper(self, m, sigma_begin, sigma_end, num_classes):
+        self.noise_in_cond = bool(getattr(m, "noise_in_cond", False))
+        self.cond_noise_fn = None        # tests inject the draw of noise_in_cond here: fn(cond) -> raw noise tensor
+        self.cond_generator = None
+        # schedule buffers exactly as the reference builds them (CPU float32)
+        dist = getattr(m, "sigma_dist", "linear")
+        if dist == "linear":
+            self.betas = torch.linspace(sigma_begin, sigma_end, num_classes)
+            self.alphas = torch.cumprod(1 - self.betas.flip(0), 0).flip(0)
+            self.alphas_prev = torch.cat([self.alphas[1:], torch.tensor([1.0]).to(self.alphas)])
+        elif dist == "cosine":           # models/__init__.py:29-33 (get_sigmas) are the alphas, betas derived
+            T = num_classes
+            t = torch.linspace(T, 0, T + 1) / T
+            f = torch.cos((t + 0.008) / (1 + 0.008) * math.pi / 2) ** 2
+            self.alphas = f[:-1] / f[-1]
+            self.alphas_prev = torch.cat([self.alphas[1:], torch.tensor([1.0]).to(self.alphas)])
+            self.betas = 1 - self.alphas / self.alphas_prev
+        else:
+            raise NotImplementedError(f"sigma_dist {dist!r}: the reference builds its buffers for 'linear' and 'cosine' only")
+        self.gamma = bool(getattr(m, "gamma", False))
+        if self.gamma:       # Gamma-noise schedule buffers (read by the samplers' gamma=True branch)
+            self.theta_0 = 0.001
+            self.k = self.betas / (self.alphas * (self.theta_0 ** 2))
+            self.k_cum = torch.cumsum(self.k.flip(0), 0).flip(0)
+            self.theta_t = torch.sqrt(self.alphas) * self.theta_0
+
+    def _noised_cond(self, cond, vals):
+        """noise_in_cond: cond <- sqrt(a) cond + sqrt(1 - a) z with a = alphas[label] per sample, z Gaussian -- or, on a
+        gamma model, a standardised Gamma(k_cum[label], rate 1/theta_t[label]) draw -- fresh on every call, as the reference
+        draws it in every forward.  ``cond_noise_fn`` (tests) supplies the raw draw."""
+        if not self.noise_in_cond or cond is None:
+            return cond
+        if any(v != int(v) or v < 0 for v in vals):
+            raise IndexError("noise_in_cond indexes the schedule with the labels (alphas[labels]): integer labels only")
+        raw = None if self.cond_noise_fn is None else self.cond_noise_fn(cond).to(self.device, torch.float32).contiguous()
+        out = torch.empty_like(cond)
+        start = 0
+        while start < len(vals):                     # runs of equal labels (the samplers: one run)
+            end = start
+            while end < len(vals) and vals[end] == vals[start]:
+                end += 1
+            i = int(vals[start])
+            a = self.alphas[i]
+            c = cond[start:end].contiguous()
+            if self.gamma:
+                from .sampler import _gamma_noise
+                z = _gamma_noise(c, self.k_cum[i], self.theta_t[i], a, raw=None if raw is None else raw[start:end],
+                                 generator=self.cond_generator)
+            elif raw is not None:
+                z = raw[start:end].contiguous()
+            else:
+                z = torch.randn(c.shape, device=self.device, dtype=torch.float32, generator=self.cond_generator)
+            out[start:end] = L.lincomb4([c, z], [float(a.sqrt()), float((1 - a).sqrt())])
+            start = end
+        return out
+
+
+class ScoreNet(DdpmWrapper):
     """HIP implementation of ``UNetMore_DDPM`` (eval mode, dropout 0), incl. its cond_emb / noise_in_cond / gamma / cosine-schedule
     options (ncsnpp_more.py:61,97-99,282-285,735-768)."""
 
@@ -128,34 +190,11 @@ class ScoreNet:
                                       "archs are not (SURVEY.md section 2); output_all_frames fails in the reference itself "
                                       "(ncsnpp_more.py:384-385 splits 15 channels into 6 + 15)")
         # cond_emb: the time embedding is extended by an Embedding(2, ngf // 2) row chosen by cond_mask (ncsnpp_more.py:97-99,
-        # :282-285); noise_in_cond: the conditioning frames are noised to the step's level before every forward (:753-768)
+        # :282-285); noise_in_cond, the schedule (linear / cosine) and the Gamma buffers: DdpmWrapper
         self.cond_emb = bool(getattr(m, "cond_emb", False))
-        self.noise_in_cond = bool(getattr(m, "noise_in_cond", False))
+        self._init_wrapper(m, self.d.sigma_begin, self.d.sigma_end, self.d.num_classes)
         if (self.cond_emb or self.noise_in_cond) and self.SPADE:
             raise NotImplementedError("cond_emb / noise_in_cond are built for the concat-conditioned network only")
-        self.cond_noise_fn = None        # tests inject the draw of noise_in_cond here: fn(cond) -> raw noise tensor
-        self.cond_generator = None
-        # schedule buffers exactly as ncsnpp_more.py:735-743 builds them (CPU float32; the samplers index them)
-        dist = getattr(m, "sigma_dist", "linear")
-        if dist == "linear":
-            self.betas = torch.linspace(self.d.sigma_begin, self.d.sigma_end, self.d.num_classes)
-            self.alphas = torch.cumprod(1 - self.betas.flip(0), 0).flip(0)
-            self.alphas_prev = torch.cat([self.alphas[1:], torch.tensor([1.0]).to(self.alphas)])
-        elif dist == "cosine":           # models/__init__.py:29-33 (get_sigmas) + ncsnpp_more.py:740-743
-            T = self.d.num_classes
-            t = torch.linspace(T, 0, T + 1) / T
-            f = torch.cos((t + 0.008) / (1 + 0.008) * math.pi / 2) ** 2
-            self.alphas = f[:-1] / f[-1]
-            self.alphas_prev = torch.cat([self.alphas[1:], torch.tensor([1.0]).to(self.alphas)])
-            self.betas = 1 - self.alphas / self.alphas_prev
-        else:
-            raise NotImplementedError(f"sigma_dist {dist!r}: UNetMore_DDPM builds its buffers for 'linear' and 'cosine' only")
-        self.gamma = bool(getattr(m, "gamma", False))
-        if self.gamma:       # Gamma-noise schedule buffers, ncsnpp_more.py:744-749 (read by the samplers' gamma=True branch)
-            self.theta_0 = 0.001
-            self.k = self.betas / (self.alphas * (self.theta_0 ** 2))
-            self.k_cum = torch.cumsum(self.k.flip(0), 0).flip(0)
-            self.theta_t = torch.sqrt(self.alphas) * self.theta_0
         self.program = build_program(self.d)
         if self.SPADE:     # the conditioning frames do not enter through the input (ncsnpp_more.py:519, :593-594)
             self.program[2]["cin"] = self.d.channels * self.d.num_frames
@@ -524,36 +563,6 @@ class ScoreNet:
         with torch.cuda.graph(graph):
             out = self.forward_rows(sx, srows, scond)
         return dict(graph=graph, x=sx, rows=srows, cond=scond, out=out)
-
-    def _noised_cond(self, cond, vals):
-        """noise_in_cond (ncsnpp_more.py:755-768): cond <- sqrt(a) cond + sqrt(1 - a) z with a = alphas[label] per sample,
-        z Gaussian -- or, on a gamma model, a standardised Gamma(k_cum[label], rate 1/theta_t[label]) draw -- fresh on every
-        call, as the reference draws it in every forward.  ``cond_noise_fn`` (tests) supplies the raw draw."""
-        if not self.noise_in_cond or cond is None:
-            return cond
-        if any(v != int(v) or v < 0 for v in vals):
-            raise IndexError("noise_in_cond indexes the schedule with the labels (alphas[labels]): integer labels only")
-        raw = None if self.cond_noise_fn is None else self.cond_noise_fn(cond).to(self.device, torch.float32).contiguous()
-        out = torch.empty_like(cond)
-        start = 0
-        while start < len(vals):                     # runs of equal labels (the samplers: one run)
-            end = start
-            while end < len(vals) and vals[end] == vals[start]:
-                end += 1
-            i = int(vals[start])
-            a = self.alphas[i]
-            c = cond[start:end].contiguous()
-            if self.gamma:
-                from .sampler import _gamma_noise
-                z = _gamma_noise(c, self.k_cum[i], self.theta_t[i], a, raw=None if raw is None else raw[start:end],
-                                 generator=self.cond_generator)
-            elif raw is not None:
-                z = raw[start:end].contiguous()
-            else:
-                z = torch.randn(c.shape, device=self.device, dtype=torch.float32, generator=self.cond_generator)
-            out[start:end] = L.lincomb4([c, z], [float(a.sqrt()), float((1 - a).sqrt())])
-            start = end
-        return out
 
     def forward_label(self, x, label, cond=None):
         """All samples share one label (what every sampler does): no device->host sync."""

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import lib as L
-from .scorenet import _Act, _pad16
+from .scorenet import DdpmWrapper, _Act, _pad16
 
 ATTENTION_WIDTHS = (32, 64, 128, 192, 256)      # head widths attention_dispatch (csrc/attention.hip) instantiates
 
@@ -67,8 +67,8 @@ def build_program(ngf, mode, n_in):
            [("upblocks", j, m) for j, m in enumerate(up)]
 
 
-class UNetDDPM:
-    """HIP implementation of ``UNet_DDPM`` (eval mode, dropout 0, noise_in_cond / gamma / output_all_frames off)."""
+class UNetDDPM(DdpmWrapper):
+    """HIP implementation of ``UNet_DDPM`` (eval mode, dropout 0; output_all_frames off)."""
 
     def __init__(self, config, state_dict, device="cuda", prefix=""):
         m_ = config.model
@@ -83,10 +83,8 @@ class UNetDDPM:
                 f"fully supported.)")
         L.hip_lib()
         m, d = config.model, config.data
-        if getattr(m, "noise_in_cond", False) or getattr(m, "gamma", False) or getattr(m, "output_all_frames", False):
-            raise NotImplementedError("noise_in_cond / gamma / output_all_frames are off in configs/mine.yml")
-        if getattr(m, "sigma_dist", "linear") != "linear":
-            raise NotImplementedError("sigma_dist != linear")
+        if getattr(m, "output_all_frames", False):
+            raise NotImplementedError("output_all_frames is not built (off in configs/mine.yml)")
         self.config, self.device = config, torch.device(device)
         self.ngf = m.ngf
         self.mode = getattr(config, "mode", "deep")
@@ -96,10 +94,8 @@ class UNetDDPM:
         n_cond = d.num_frames_cond + getattr(d, "num_frames_future", 0)
         self.n_in = d.channels * (d.num_frames + n_cond)
         self.type = getattr(m, "type", "v1")
-        sb, se, nc = getattr(m, "sigma_begin", 0.02), getattr(m, "sigma_end", 1e-4), getattr(m, "num_classes", 1000)
-        self.betas = torch.linspace(sb, se, nc)                          # models/unet.py:346-349
-        self.alphas = torch.cumprod(1 - self.betas.flip(0), 0).flip(0)
-        self.alphas_prev = torch.cat([self.alphas[1:], torch.tensor([1.0]).to(self.alphas)])
+        # schedule (linear / cosine), Gamma buffers, noise_in_cond: models/unet.py:337-372, same code as UNetMore_DDPM
+        self._init_wrapper(m, getattr(m, "sigma_begin", 0.02), getattr(m, "sigma_end", 1e-4), getattr(m, "num_classes", 1000))
         self.program = build_program(self.ngf, self.mode, self.n_in)
         self._load(state_dict, prefix + "unet.")
         self._rows, self._row_bias = {}, {}
@@ -284,10 +280,15 @@ class UNetDDPM:
         L.conv2d_nhwc(h.t, self.out["w"], co, 3, 3, bias=self.out["b"], coef=coef, act_in=L.ACT_SILU, out=out)
         return L.nhwc_to_nchw(out, co)
 
-    def forward_label(self, x, label, cond=None):
-        """All samples share one label (what every sampler does)."""
+    def _forward_label(self, x, label, cond):
         self.prepare_labels([label])
         return self.forward_row(x, self._row_bias.get(float(label)), cond)
+
+    def forward_label(self, x, label, cond=None):
+        """All samples share one label (what every sampler does)."""
+        if self.noise_in_cond and cond is not None:
+            cond = self._noised_cond(cond.to(self.device, torch.float32).contiguous(), [float(label)] * x.shape[0])
+        return self._forward_label(x, label, cond)
 
     def __call__(self, x, labels, cond=None, cond_mask=None):
         """Reference call shape ``scorenet(x, labels, cond=cond)``.  The time embedding enters as a per-sample bias of
@@ -296,13 +297,14 @@ class UNetDDPM:
         assert len(vals) == x.shape[0]
         x = x.to(self.device, torch.float32).contiguous()
         cond = None if cond is None else cond.to(self.device, torch.float32).contiguous()
+        cond = self._noised_cond(cond, vals)             # noise_in_cond: per-sample levels, before the batch is regrouped
         uniq = list(dict.fromkeys(vals))
         if len(uniq) == 1 or not self.time_conditional:
-            return self.forward_label(x, uniq[0], cond)
+            return self._forward_label(x, uniq[0], cond)
         out = torch.empty((x.shape[0], self.out["co"], x.shape[2], x.shape[3]), device=self.device, dtype=torch.float32)
         for v in uniq:
             idx = torch.tensor([i for i, u in enumerate(vals) if u == v], device=self.device)
-            out[idx] = self.forward_label(x[idx].contiguous(), v, None if cond is None else cond[idx].contiguous())
+            out[idx] = self._forward_label(x[idx].contiguous(), v, None if cond is None else cond[idx].contiguous())
         return out
 
     forward = __call__

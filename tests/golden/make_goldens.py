@@ -386,6 +386,21 @@ def gen_unet_ddpm():
     assert not unexpected and all(not m.startswith("unet.") for m in missing), missing
     with torch.no_grad():
         out["out_ngf64_t500"] = net(rnd(62, 1, 15, 32, 32), torch.tensor([500]), cond=rnd(63, 1, 6, 32, 32))
+    # the wrapper options of UNet_DDPM (models/unet.py:337-372): noise_in_cond with the injected draw (mixed labels), and the
+    # cosine schedule's buffers
+    cfg = ref_config(32, 32, 32, noise_in_cond=True, sigma_dist="cosine")
+    cfg.model.time_conditional = True
+    net = UNet_DDPM(cfg).eval()
+    net.load_state_dict(OU.seeded_params(OU.Dims(ngf=32, time_conditional=True), 61), strict=False)
+    z = rnd(64, 2, 6, 32, 32)
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **kw: z
+    try:
+        with torch.no_grad():
+            out["out_nic_cos"] = net(x, torch.tensor([500, 7]), cond=cond)
+    finally:
+        torch.randn_like = orig
+    out["cos_alphas"] = net.alphas
     save("unet_ddpm", **out)
 
 

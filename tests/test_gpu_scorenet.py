@@ -498,6 +498,14 @@ def test_alt_model_unet_ddpm_against_reference_goldens():
     net = UNetDDPM(cfg, OU.seeded_params(OU.Dims(ngf=64, time_conditional=True), 64))
     out = net(rnd(62, 1, 15, 32, 32).cuda(), torch.tensor([500]), cond=rnd(63, 1, 6, 32, 32).cuda())
     assert rel(out, g["out_ngf64_t500"]) < 1e-4
+    # the wrapper options (models/unet.py:337-372, shared with UNetMore_DDPM): noise_in_cond at mixed labels + cosine schedule
+    cfg = make_config(32, 32, 32)
+    cfg.model.time_conditional, cfg.model.noise_in_cond, cfg.model.sigma_dist = True, True, "cosine"
+    net = UNetDDPM(cfg, OU.seeded_params(OU.Dims(ngf=32, time_conditional=True), 61))
+    np.testing.assert_allclose(net.alphas.numpy(), g["cos_alphas"], rtol=2e-6, atol=1e-9)
+    net.alphas = torch.from_numpy(g["cos_alphas"].copy())                    # cos() differs by an ulp between hosts
+    net.cond_noise_fn = lambda c: rnd(64, 2, 6, 32, 32)
+    assert rel(net(x, torch.tensor([500, 7]), cond=cond), g["out_nic_cos"]) < 1e-4
 
 
 def build_spade(ngf, head, image_size, seed, spade_dim):
