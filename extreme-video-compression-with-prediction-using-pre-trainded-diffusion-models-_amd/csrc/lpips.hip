@@ -2,8 +2,8 @@
 //
 // The sender's decision rule compares generated frames with the originals by LPIPS (reference city_sender.py:302 builds
 // lpips.LPIPS(net='alex'), :376-406 decide_5to5_lpips keeps a frame while the distance stays under the threshold).  The
-// metric itself lives in the third-party packages lpips==0.1.4 (requirements.txt:66) and torchvision (AlexNet), neither
-// in the reference tree; its published algorithm, restated in oracle/lpips.py:
+// algorithm as the reference vendors it (models/networks_basic.py:62-93 PNetLin.forward + ScalingLayer, models/eval_models.py:35-37
+// normalize_tensor, models/pretrained_networks.py:56-94 AlexNet slices; restated in oracle/lpips.py):
 //     x -> (x - shift) / scale                                            (ScalingLayer, per RGB channel)
 //     AlexNet features: conv 11x11 s4 p2 (3->64) ReLU | maxpool 3 s2, conv 5x5 p2 (64->192) ReLU |
 //                       maxpool 3 s2, conv 3x3 (192->384) ReLU | conv 3x3 (384->256) ReLU | conv 3x3 (256->256) ReLU

@@ -1,12 +1,12 @@
 """LPIPS (AlexNet, v0.1) on the HIP kernels: the perceptual distance of the sender's decision rule.
 
 Mirrors ``lpips.LPIPS(net='alex')`` as the reference builds and calls it (``city_sender.py:302``; ``decide_5to5_lpips``,
-``:376-406``: one (3, H, W) frame pair at a time, [0, 1] data passed as is).  The metric belongs to third-party packages
-(lpips==0.1.4 on torchvision's AlexNet) that are not part of the reference tree; what is built is their published algorithm
-(oracle/lpips.py restates it).  The trained weights cannot be fetched offline: ``LpipsAlex`` takes a state dict in the
-packages' own key names -- ``features.{0,3,6,8,10}.{weight,bias}`` (torchvision ``alexnet``) plus ``lin{k}.model.1.weight``
-(lpips ``weights/v0.1/alex.pth``; the ``lins.{k}.`` and ``net.slice*`` spellings of a saved ``LPIPS`` module are accepted too) --
-or the two files themselves (``from_files``).
+``:376-406``: one (3, H, W) frame pair at a time, [0, 1] data passed as is).  The algorithm is the one the reference vendors in
+``models/networks_basic.py:62-93`` (``PNetLin.forward``, ``ScalingLayer``), ``models/eval_models.py:35-37`` and
+``models/pretrained_networks.py:56-94`` (oracle/lpips.py restates it).  Weights: ``LpipsAlex`` takes a state dict in the packages'
+own key names -- ``features.{0,3,6,8,10}.{weight,bias}`` (torchvision ``alexnet``; not in the reference tree, cannot be fetched
+offline) plus ``lin{k}.model.1.weight`` (the reference's ``weights/v0.1/alex.pth``; the ``lins.{k}.`` and ``net.slice*``
+spellings of a saved ``LPIPS`` module are accepted too) -- or the two files themselves (``from_files``).
 
 Data path: NCHW frames -> ``evc_im2col_nchw_f32`` (ScalingLayer + 11x11 stride-4 patches) -> 1x1 convolution, then
 ``evc_maxpool3s2_nhwc_f32`` and 5x5 / 3x3 convolutions, all on ``evc_conv2d_nhwc_f32`` with the exact bf16 split (the inputs are

@@ -301,9 +301,9 @@ int evc_conv5x5s2_f32(const float* x, int ld_in, const void* w_packed, int arith
                       int B, int Ho, int Wo, int Ci, int Co, int act_out, void* stream);
 
 /* ---- LPIPS (AlexNet, v0.1): the perceptual distance of the sender's decision rule ------------------------------
- * Replaces lpips.LPIPS(net='alex') as built by city_sender.py:302 and called by decide_5to5_lpips (:376-406).  The
- * metric is third-party code (lpips==0.1.4, requirements.txt:66, on torchvision's AlexNet; neither is in the reference
- * tree): its published algorithm is restated in oracle/lpips.py.  The five convolutions run on evc_conv2d_nhwc_f32; these
+ * Replaces lpips.LPIPS(net='alex') as built by city_sender.py:302 and called by decide_5to5_lpips (:376-406); the
+ * algorithm is the one vendored in models/networks_basic.py:62-93 (PNetLin.forward, ScalingLayer), models/eval_models.py:35-37
+ * (normalize_tensor) and models/pretrained_networks.py:56-94 (AlexNet slices), restated in oracle/lpips.py.  The five convolutions run on evc_conv2d_nhwc_f32; these
  * are the other pieces (csrc/lpips.hip):
  *   evc_im2col_nchw_f32   x (N, C, H, W) NCHW -> out (N, Ho, Wo, ld_out) rows of KH*KW patches in (c, ky, kx) order, the
  *                         columns C*KH*KW .. ld_out-1 zero; optional per-channel (x - shift[c]) / scale[c] (the ScalingLayer)

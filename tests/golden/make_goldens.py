@@ -279,6 +279,14 @@ def gen_model_options():
     save("model_options", **out)
 
 
+def gen_lpips_lin():
+    """The trained linear layers of LPIPS-AlexNet v0.1 as the reference ships them (weights/v0.1/alex.pth; identical copies under
+    models/weights and benchmark/weights), read with the weights-only loader: five non-negative vectors, 1 152 floats.  The
+    AlexNet backbone they sit on is torchvision's pretrained checkpoint, which the reference does not hold."""
+    sd = torch.load(os.path.join(REF, "weights/v0.1/alex.pth"), map_location="cpu", weights_only=True)
+    save("lpips_alex_lin", **{f"lin{i}": sd[f"lin{i}.model.1.weight"].reshape(-1) for i in range(5)})
+
+
 def gen_forward_full():
     torch.set_num_threads(8)
     net, d = ref_net(192, 192, 128, 1234)
@@ -437,7 +445,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     gens = dict(schedule=gen_schedule, fir=gen_fir, blocks=gen_blocks, forward_reduced=gen_forward_reduced,
-                samplers=gen_samplers, sampler_options=gen_sampler_options, sampler_gamma=gen_sampler_gamma, model_options=gen_model_options,
+                samplers=gen_samplers, sampler_options=gen_sampler_options, sampler_gamma=gen_sampler_gamma, model_options=gen_model_options, lpips_lin=gen_lpips_lin,
                 forward_full=gen_forward_full, forward_full_b9=gen_forward_full_b9,
                 traj_full=gen_traj_full, traj_fpndm_full=gen_traj_fpndm_full, unet_ddpm=gen_unet_ddpm, forward_spade=gen_forward_spade)
     for name, fn in gens.items():

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rnd
+from conftest import golden, rnd
 
 pytestmark = pytest.mark.gpu
 
@@ -169,7 +169,7 @@ def _policy_sweep_against_the_oracle(kind):
     if lp:
         from evc_amd.lpips import LpipsAlex
         from oracle import lpips as OL
-        sd = OL.seeded_state_dict(8)
+        sd = OL.seeded_state_dict(8, golden("lpips_alex_lin"))          # the reference's trained linear layers
         distance = lambda a, b: float(OL.distance(sd, a[None].float(), b[None].float())[0])
         hip_lpips = LpipsAlex(sd)
         metric = P.CallableMetric(lambda a, b: hip_lpips(a, b), name="lpips-alex-hip")

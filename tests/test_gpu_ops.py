@@ -750,14 +750,17 @@ def test_im2col_and_maxpool_against_torch():
 
 
 def test_lpips_alexnet_against_the_oracle():
-    """LPIPS(net='alex') (city_sender.py:302, :376-406) on the HIP kernels vs the CPU restatement of the lpips 0.1.4 /
-    torchvision algorithm (oracle/lpips.py; PARITY UNPINNED: neither package nor its weights exist here) in float64, seeded
-    stand-in weights in the packages' own layouts: per-pair distances, the single-frame call form of the reference, d(x, x) = 0,
-    the key spellings of a saved LPIPS module."""
+    """LPIPS(net='alex') (city_sender.py:302, :376-406) on the HIP kernels vs the CPU restatement of the algorithm the
+    reference vendors (models/networks_basic.py:62-93, oracle/lpips.py) in float64, under the reference's own trained linear
+    layers (weights/v0.1/alex.pth -> tests/golden/lpips_alex_lin.npz) and seeded stand-ins for the AlexNet convolutions
+    (torchvision's checkpoint is not in the reference tree: backbone weights unpinned): per-pair distances, the single-frame
+    call form of the reference, d(x, x) = 0, the key spellings of a saved LPIPS module."""
     import evc_amd  # noqa: F401
     from evc_amd.lpips import LpipsAlex
     from oracle import lpips as OL
-    sd = OL.seeded_state_dict(5)
+    lin = golden("lpips_alex_lin")
+    assert all(float(lin[f"lin{i}"].min()) >= 0.0 for i in range(5))          # the trained layers are non-negative
+    sd = OL.seeded_state_dict(5, lin)
     net = LpipsAlex(sd)
     a = torch.rand(5, 3, 128, 128, generator=torch.Generator().manual_seed(1))
     b = (a + 0.1 * rnd(2, 5, 3, 128, 128)).clamp(0, 1)
@@ -792,7 +795,7 @@ def test_lpips_policy_metric_from_weight_files(tmp_path):
     import evc_amd  # noqa: F401
     from evc_amd import policy as P
     from oracle import lpips as OL
-    sd = OL.seeded_state_dict(6)
+    sd = OL.seeded_state_dict(6, golden("lpips_alex_lin"))
     torch.save({k: v for k, v in sd.items() if k.startswith("features.")}, tmp_path / "alexnet.pth")
     torch.save({k: v for k, v in sd.items() if k.startswith("lin")}, tmp_path / "alex.pth")
     m = P.load_metric("lpips", f"{tmp_path / 'alexnet.pth'},{tmp_path / 'alex.pth'}", "cuda")

@@ -189,7 +189,9 @@ def test_lpips_oracle_basic_properties():
     of a 128x128 frame, zero distance of identical images, symmetry, growth with the perturbation."""
     import torch
     from oracle import lpips as OL
-    sd = OL.seeded_state_dict(5)
+    lin = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lpips_alex_lin.npz"))
+    assert [lin[f"lin{i}"].shape[0] for i in range(5)] == list(OL.CHANNELS)       # weights/v0.1/alex.pth of the reference
+    sd = OL.seeded_state_dict(5, lin)
     x = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(0))
     taps = OL.features(sd, x)
     assert [tuple(t.shape[1:]) for t in taps] == [(64, 31, 31), (192, 15, 15), (384, 7, 7), (256, 7, 7), (256, 7, 7)]
