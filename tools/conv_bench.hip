@@ -184,6 +184,12 @@ int main(int argc, char** argv) {
             a.src0 = x; a.C0 = s.Ci; a.w_packed = (const float*)wp[arith]; a.out = o[arith]; a.ld_out = s.Co; a.out_scale = 1.f;
             a.B = s.B; a.H = s.R; a.W = s.R; a.Co = s.Co; a.KH = s.K; a.KW = s.K; a.arith = arith;
             if (s.mode) { a.coef_a = ca; a.coef_s = cs; a.act_in = EVC_ACT_SILU; }
+            static float* epi_stats = nullptr;
+            if (getenv("EVC_BENCH_EPI")) {       // the epilogue of a res-block's Conv_1: fused moments, residual, 1/sqrt(2)
+                if (!epi_stats) CK(hipMalloc(&epi_stats, (size_t)32 * 16384 / 64 * 1536 * 2 * 4));
+                a.stats_out = epi_stats; a.out_scale = 0.70710678f;
+                if (s.Ci == s.Co && atoi(getenv("EVC_BENCH_EPI")) > 1) { a.res = x; a.ld_res = s.Ci; }
+            }
             long long wsb = evc_conv_workspace_bytes(&a);
             ws = nullptr;
             if (wsb > 0) CK(hipMalloc(&ws, wsb));
