@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clips", type=int, default=9, help="clips per GPU per step (configs[1]: start 0 end 8)")
+    ap.add_argument("--total-clips", type=int, default=0,
+                    help="fixed JOB size instead of --clips per GPU: the clips are block-sharded over the ranks "
+                         "(evc_amd.dist.shard_range: 46 over 8 -> 6,6,6,6,6,6,5,5 = BASELINE configs[2]; 256 with "
+                         "--sampler FPNDM --subsample 50 = configs[4]); reported as strong scaling")
     ap.add_argument("--subsample", type=int, default=100)
     ap.add_argument("--sampler", default="DDPM", choices=["DDPM", "DDIM", "FPNDM"])
     ap.add_argument("--groups", type=int, default=1,
@@ -147,8 +151,14 @@ def roofline_leg(net, clips, device):
         else:
             name = (f"conv_splitn_kernel<2, *, {r['variant']}, {mode_of(c)}>" if np_ == 2 else
                     f"conv_split_kernel<*, {r['variant']}, {mode_of(c)}>")
-        kv = kern.setdefault((name, r["arith"]), dict(n=0, ms=0.0, ms_all=0.0, flops=0.0))
+        kv = kern.setdefault((name, r["arith"]), dict(n=0, ms=0.0, ms_all=0.0, flops=0.0, bytes=0.0))
         kv["n"] += 1; kv["ms"] += ms_k; kv["ms_all"] += ms_all; kv["flops"] += r["flops"]
+        # algorithmic HBM bytes of the launch: every operand read once, the output written once (fp32 activations, the
+        # packed weights as they are stored: two fp16 / three bf16 planes or fp32)
+        M = c["B"] * c["H"] * c["W"]
+        wbytes = {0: 4, 1: 6, 2: 4}[r["arith"]]
+        kv["bytes"] += (4.0 * M * (c["C0"] + c["C1"] + c["x2"] + c["Co"] * (2 if c["res"] else 1))
+                        + wbytes * c["Co"] * (c["K"] * c["K"] * (c["C0"] + c["C1"]) + c["x2"]))
     total_ms = sum(v["ms"] for v in per.values()) / reps
     total_flops = sum(v["flops"] for v in per.values()) / reps
     # THE dominant kernel: the template instance with the largest share of the convolution time.  achieved = its algorithmic
@@ -163,6 +173,7 @@ def roofline_leg(net, clips, device):
            "frac": round(achieved / peak, 4), "traffic": None, "kernel": dk_name, "peak_basis": basis,
            "launches_per_forward": dk["n"] // reps, "avg_launch_us": round(us, 2),
            "algorithmic_gflop_per_launch": round(gflop, 3),
+           "algorithmic_bytes_per_launch": int(dk["bytes"] / dk["n"]),
            "avg_launch_us_incl_combine": round(dk["ms_all"] / dk["n"] * 1e3, 2),
            "share_of_conv_time": round(dk["ms_all"] / reps / total_ms, 3),
            "achieved_over_f32_mfma_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 3)}
@@ -201,6 +212,7 @@ def roofline_leg(net, clips, device):
             prov = f"profiles/r03_conv_{aname}_pmc.json covers {pmc.get('kernel')} at B={pmc.get('batch')}"
         else:
             out["traffic"] = pmc["hbm_bytes_per_launch"]
+            out["traffic_over_algorithmic_bytes"] = round(pmc["hbm_bytes_per_launch"] / (dk["bytes"] / dk["n"]), 2)
             prov = f"profiles/r03_conv_{aname}_pmc.json, source {pmc['source_sha']}, FETCH_SIZE x2 + WRITE_SIZE"
     except Exception:
         pass
@@ -217,10 +229,11 @@ def roofline_leg(net, clips, device):
                        for (a, t), v in sorted(per.items())}
     out["batch"] = clips
     out["note"] = ("launch durations measured with the res-block side stream OFF (launches one after another; the timed region "
-                   "runs with it on); `families` / conv_ms_per_forward include the split-K combine launches; under sustained "
-                   "launches of this kernel the package sits at its 1 400 W power cap at 1.83 GHz (profiles/r03_power_cap.log), "
-                   "63 % of the energy in the MFMAs (profiles/r03_conv_mfma_count_ablation.log): frac is bounded by energy per "
-                   "product, not by issue slots")
+                   "runs with it on); `families` / conv_ms_per_forward include the split-K combine launches.  Inside a forward the "
+                   "heavy convolution launches alternate with light kernels: the package averages ~1 000 W of its 1 400 W cap and "
+                   "holds ~2.05 GHz (held_clock_ghz), so frac is bounded by CYCLES -- non-MFMA work per MFMA in the K loop "
+                   "(operand staging, weight delivery, fragment reads; DESIGN.md section 9) -- not by the power cap; only "
+                   "back-to-back launches of this kernel alone reach the cap (1.83 GHz, profiles/r03_power_cap.log)")
     return out
 
 
@@ -360,6 +373,26 @@ def cpu_baseline_leg(sd_d, sd_e, seconds):
                     "included"}
 
 
+def rank_clips(a, rank, world):
+    """-> (clips this rank decodes per step, config.workload text, scaling).  ``--clips`` per GPU is weak scaling (the
+    driver's contract); ``--total-clips`` is a fixed job block-sharded over the ranks (BASELINE configs[2] / [4])."""
+    from evc_amd import dist as D
+    fwd = {"DDPM": a.subsample + 1, "DDIM": a.subsample + 1, "FPNDM": 12 + (a.subsample - 3)}[a.sampler]
+    tail = f"x 30 frames 128x128, q3, 2 ELIC key frames + 6 chunks x {fwd} forwards ({a.sampler}-{a.subsample})"
+    if a.total_clips > 0:
+        lo, hi = D.shard_range(a.total_clips, rank, world)
+        sizes = [D.shard_range(a.total_clips, r, world) for r in range(world)]
+        plan = ",".join(str(h - l) for l, h in sizes)
+        name = "custom"
+        if (a.total_clips, a.sampler, a.subsample) == (46, "DDPM", 100):
+            name = "configs[2]"
+        elif (a.total_clips, a.sampler, a.subsample) == (256, "FPNDM", 50):
+            name = "configs[4]"
+        return hi - lo, f"{name}: {a.total_clips} clips over {world} rank(s) ({plan}) {tail}, one launch batch per rank", "strong"
+    name = "configs[1]" if (a.clips, a.sampler, a.subsample) == (9, "DDPM", 100) else "custom"
+    return a.clips, f"{name}: {a.clips} clips/GPU {tail}, B={a.clips} per launch", "weak"
+
+
 def plumbing_only(a, D):
     """Multi-rank plumbing without the GPU path: what a CPU (gloo) test can assert about `bench.py --gpus N`."""
     rank, world, device = D.init()
@@ -377,10 +410,13 @@ def plumbing_only(a, D):
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
     seen = int(D.sum_over_ranks(1, device))
+    n_own, workload, scaling = rank_clips(a, rank, world)
+    per_rank_clips = [int(v) for v in D.gather_over_ranks(n_own, device)]
     if rank == 0:
         print(json.dumps({"metric": "decoded frames/sec (128x128x30) at q3", "value": None, "unit": "frames/s",
                           "n_gpus": world, "ranks_seen": seen, "backend": D.backend_name(), "plumbing_only": True,
-                          "broadcast_ok": ok, "barrier_s": elapsed,
+                          "broadcast_ok": ok, "barrier_s": elapsed, "per_rank_clips": per_rank_clips, "scaling": scaling,
+                          "config": {"workload": workload},
                           "self_launched": os.environ.get("EVC_SELF_LAUNCHED") == "1"}), flush=True)
     D.barrier()
     return 0 if ok and seen == world else 1
@@ -423,7 +459,11 @@ def main():
     dec = ClipDecoder(net, elic, cfg, S.get_sampler(a.sampler), groups=a.groups)
 
     # inputs: this rank's clips; key frames 0,1 are ELIC-encoded once (sender side, untimed)
-    clips = torch.from_numpy(synthetic.make_clips(a.clips, seed=100 + rank).astype(np.float32) / 255.0)
+    n_own, workload, scaling = rank_clips(a, rank, world)
+    if n_own < 1:
+        print(f"error: rank {rank} of {world} has no clip to decode (--total-clips {a.total_clips})", file=sys.stderr)
+        sys.exit(2)
+    clips = torch.from_numpy(synthetic.make_clips(n_own, seed=100 + rank).astype(np.float32) / 255.0)
     key_strings, shape = [], None
     for f in range(2):
         enc = elic.compress(clips[:, f].to(device))
@@ -447,7 +487,10 @@ def main():
     torch.cuda.synchronize()
     # shader clock the chip holds during the timed region (it runs into the package power cap under the convolutions): an
     # idle one-wave probe on its own stream that ends with the region (or after 9 s of it)
-    probe = L.ClockProbe(int(min(9.0, t_warm * a.steps) * 1e6), device) if (rank == 0 and t_warm) else None
+    # (skipped with --graphs / --groups > 1: HIP streams can then share a hardware queue with the probe's stream and work
+    # queued behind the parked probe kernel would stall until it times out -- ADVICE r3)
+    probe = (L.ClockProbe(int(min(9.0, t_warm * a.steps) * 1e6), device)
+             if (rank == 0 and t_warm and not a.graphs and a.groups == 1) else None)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         frames = step()
@@ -459,9 +502,13 @@ def main():
     clock_ghz = probe.ghz() if probe is not None else None
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
-    per_rank = [round(a.clips * 30 * a.steps / t, 3) for t in D.gather_over_ranks(own_elapsed, device)]
-    events = int(D.sum_over_ranks(L.range_events(), device))
-    assert frames.shape == (a.clips, 30, 3, 128, 128) and bool(torch.isfinite(frames).all())
+    per_rank_clips = [int(v) for v in D.gather_over_ranks(n_own, device)]
+    per_rank = [round(c * 30 * a.steps / t, 3) for c, t in zip(per_rank_clips, D.gather_over_ranks(own_elapsed, device))]
+    # the range-event word is a bit mask: OR over the ranks (a sum of N ranks' bit 1 would read as another bit)
+    events = 0
+    for v in D.gather_over_ranks(L.range_events(), device):
+        events |= int(v)
+    assert frames.shape == (n_own, 30, 3, 128, 128) and bool(torch.isfinite(frames).all())
     seen = int(D.sum_over_ranks(1, device))
 
     # how much of a step is ELIC key-frame decoding (latency-bound: 10 host round trips per batch)
@@ -473,10 +520,10 @@ def main():
     torch.cuda.synchronize()
     elic_ms = (time.perf_counter() - te) * 1e3
 
-    n_frames = world * a.clips * 30 * a.steps
+    n_frames = sum(per_rank_clips) * 30 * a.steps
     value = n_frames / elapsed
     fwd_per_chunk = {"DDPM": a.subsample + 1, "DDIM": a.subsample + 1, "FPNDM": 12 + (a.subsample - 3)}[a.sampler]
-    flop_per_step_gpu = a.clips * (6 * fwd_per_chunk * FWD_FLOP_PER_SAMPLE + 2 * ELIC_DECODE_FLOP)
+    flop_per_step_gpu = sum(per_rank_clips) / world * (6 * fwd_per_chunk * FWD_FLOP_PER_SAMPLE + 2 * ELIC_DECODE_FLOP)
     policy = {L.ARITH_F32: "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere",
               L.ARITH_BF16X6: "conv products as 6 bf16 MFMAs on an exact 3-way bf16 split of both operands",
               L.ARITH_F16X3: "score-network convolutions and attention: operands scaled by powers of two into fp16 range "
@@ -486,24 +533,27 @@ def main():
     out = {"metric": "decoded frames/sec (128x128x30) at q3", "value": round(value, 4), "unit": "frames/s",
            "n_gpus": world, "ranks_seen": seen, "backend": D.backend_name(),
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "arithmetic": "fp32 in / fp32 accumulate, fp32-equivalent products (error vs fp64 <= the f32-MFMA path, "
                          "tests/test_gpu_ops.py): " + policy,
-           "config": {"workload": f"{'configs[1]' if (a.clips, a.sampler, a.subsample) == (9, 'DDPM', 100) else 'custom'}: "
-                                  f"{a.clips} clips/GPU x 30 frames 128x128, q3, 2 ELIC key frames + "
-                                  f"6 chunks x {fwd_per_chunk} forwards ({a.sampler}-{a.subsample}), B={a.clips} per launch",
+           "config": {"workload": workload,
                       "parallelism": f"clip-sharded dp{world}, no data-path collective; {a.groups} concurrent clip "
                                      f"group(s) per GPU; forwards {'replayed from HIP graphs' if a.graphs else 'launched eagerly'}",
                       "weights": "seeded random, reference architecture (262.1M + ELIC)"},
-           "per_rank_value": per_rank, "range_events": events,
-           "timed_region_shader_clock_ghz": None if clock_ghz is None else round(clock_ghz, 3),
+           "per_rank_value": per_rank, "per_rank_clips": per_rank_clips, "range_events": events,
+           "range_events_note": "bitwise OR over the ranks of the sticky EVC_RANGE_* word (include/evc_hip.h); 0 = no NaN / inf in any "
+                                "tensor and every GroupNorm-ed or moment-bounded fp16-split operand of the score network provably in range",
+           "timed_region_first_9s_shader_clock_ghz": None if clock_ghz is None else round(clock_ghz, 3),
            "timed_region_end_package_power_w": None if power_w is None else round(power_w),
            "whole_path_tflops_per_gpu": round(flop_per_step_gpu * a.steps / elapsed / 1e12, 2),
+           "whole_path_frac": round(flop_per_step_gpu * a.steps / elapsed / 1e12 / ARITH_INFO[L.bounded_arith()][1], 4),
+           "whole_path_frac_note": "whole-job algorithmic FLOP/s per GPU (forwards + ELIC, everything between the barriers) over the "
+                                   "roof of the convolution arithmetic in use (f16x3: 833.3)",
            "elic_keyframe_decode_ms_per_step": round(elic_ms, 1)}
     if rank == 0:
         progress(f"timed region: {elapsed:.2f} s for {a.steps} step(s) -> {value:.2f} frames/s; roofline + HBM probes")
-        out["roofline"] = roofline_leg(net, a.clips, device)
-        out["hbm_classes"] = hbm_classes_leg(a.clips, device)
+        out["roofline"] = roofline_leg(net, n_own, device)
+        out["hbm_classes"] = hbm_classes_leg(n_own, device)
         # the CPU baseline runs at N = 1 only: with more ranks the others would wait in a collective for minutes (under
         # torchrun OMP_NUM_THREADS=1 makes it slower still) while the result line is already known
         out["cpu_baseline"] = None if (a.no_cpu_baseline or world > 1) else cpu_baseline_leg(sd_d, sd_e, a.cpu_baseline_seconds)

@@ -5,10 +5,11 @@
 
 Differences, all additive: ``--q`` selects ELIC quality indexes (the reference hard-codes 4 and 5,
 city_sender.py:504), ``--sampler DDPM|DDIM|FPNDM``, ``--policy mask|psnr|lpips`` (+ ``--thresholds``, ``--metric``):
-``lpips`` is the reference's rule (``decide_5to5_lpips``, city_sender.py:376-406, thresholds 0.30 ... 0.03) and needs a
-perceptual metric -- the ``lpips`` package with torchvision's pretrained AlexNet, or ``--metric pkg.module:callable``;
-neither can be fetched offline, so ``psnr`` (the reference's own ``decide_5to5``, city_sender.py:353-374) is the
-tested rule and ``mask`` a fixed transmit mask; ``--synthetic`` builds seeded stand-ins when checkpoints / data are
+``lpips`` is the reference's rule (``decide_5to5_lpips``, city_sender.py:376-406, thresholds 0.30 ... 0.03 x q in {4, 5}) and
+the DEFAULT whenever a perceptual metric is available -- ``--metric`` (weight files of the HIP LPIPS-AlexNet or
+``pkg.module:callable``) or LPIPS weight files found where the reference keeps them (``find_lpips_weights``); without one
+the explicit fallback ``mask`` (fixed transmit mask) runs and the CLI says so; ``psnr`` is the reference's own
+``decide_5to5`` (city_sender.py:353-374); ``--synthetic`` builds seeded stand-ins when checkpoints / data are
 absent.  ``--gpus N`` (or ``torch.distributed.run``) block-shards the video range over N ranks, one GPU each.
 """
 import argparse
@@ -47,7 +48,11 @@ def build_parser():
     # --- additions ---
     p.add_argument("--q", type=int, nargs="+", default=[4, 5], help="ELIC quality indexes (reference loop: 4 5)")
     p.add_argument("--sampler", default="DDPM", choices=["DDPM", "DDIM", "FPNDM"])
-    p.add_argument("--policy", default="mask", choices=["mask", "psnr", "lpips"])
+    p.add_argument("--policy", default=None, choices=["mask", "psnr", "lpips"],
+                   help="default: lpips -- the reference's rule (decide_5to5_lpips over thresholds 0.30 ... 0.03 x q in {4, 5}, "
+                        "city_sender.py:376-406,504-548) -- when --metric is given or LPIPS weight files are found "
+                        "(weights/v0.1/alex.pth + an alexnet-owt-*.pth backbone beside it or in the torch hub cache); "
+                        "otherwise the explicit fallback `mask` (fixed transmit mask).  The rule that ran is printed.")
     p.add_argument("--thresholds", type=float, nargs="+", default=None,
                    help="psnr policy: dB thresholds; lpips policy: distances (default: the reference's sweep "
                         "0.30, 0.29 ... 0.03, city_sender.py:508)")
@@ -70,6 +75,57 @@ def build_parser():
                    help="mask policy: write each batch's key-frame strings + mask as an EVC1 container here and "
                         "decode from the bytes read back (container.py)")
     return p
+
+
+def find_lpips_weights(roots=(".",)):
+    """The LPIPS weight files the reference's rule needs, where the reference keeps / fetches them: the trained linear
+    layers ``weights/v0.1/alex.pth`` (shipped in the reference tree, also under models/ and benchmark/) and torchvision's
+    AlexNet backbone ``alexnet-owt-*.pth`` (beside it, or in the torch hub cache where ``lpips.LPIPS(net='alex')`` downloads
+    it).  -> "backbone.pth,alex.pth" (the ``--metric`` spec of the HIP LPIPS network) or None."""
+    import glob as _glob
+    for root in roots:
+        for sub in ("weights/v0.1", "models/weights/v0.1", "benchmark/weights/v0.1"):
+            lin = os.path.join(root, sub, "alex.pth")
+            if not os.path.isfile(lin):
+                continue
+            hub = os.path.join(os.environ.get("TORCH_HOME", os.path.expanduser("~/.cache/torch")), "hub", "checkpoints")
+            for d in (os.path.join(root, sub), hub):
+                back = sorted(_glob.glob(os.path.join(d, "alexnet-owt-*.pth")))
+                if back:
+                    return f"{back[0]},{lin}"
+    return None
+
+
+def resolve_policy(args, log=print):
+    """The decision rule of this run.  An explicit ``--policy`` wins; otherwise the reference's own rule (LPIPS thresholds
+    0.30 ... 0.03, city_sender.py:376-406,504-548) whenever a perceptual metric is available, else ``mask``."""
+    if args.policy is None:
+        if args.metric is None:
+            args.metric = find_lpips_weights()
+        args.policy = "lpips" if args.metric else "mask"
+        why = (f"metric {args.metric}" if args.metric else
+               "no --metric and no LPIPS weight files (weights/v0.1/alex.pth + alexnet-owt-*.pth) found: explicit fallback")
+        log(f"decision rule: {args.policy} ({why})")
+    else:
+        log(f"decision rule: {args.policy} (--policy)")
+    return args.policy
+
+
+class NumericsError(RuntimeError):
+    pass
+
+
+def check_numerics(frames, where):
+    """The fp16-split arithmetic clamps nothing (include/evc_hip.h EVC_RANGE_*): an operand beyond fp16's range becomes NaN
+    and the sticky range-event word says so.  Never write such frames: stop with the remedy."""
+    from . import lib as L
+    ev = L.range_events(reset=True)
+    finite = bool(torch.isfinite(frames).all()) if torch.is_tensor(frames) else bool(np.isfinite(frames).all())
+    if ev or not finite:
+        raise NumericsError(
+            f"{where}: range-event word {ev:#x}, frames finite: {finite}.  A GroupNorm-ed or moment-bounded operand of the "
+            f"score network left fp16's range (or a tensor held NaN / inf) under the default f16x3 arithmetic; rerun with "
+            f"EVC_CONV_ARITH=bf16x6 (exact 3-way bf16 split, no range assumption; about half the throughput) or =f32")
 
 
 def cal_psnr(a, b, maxvalue=1.0):
@@ -103,6 +159,7 @@ def main(argv=None):
     from .elic import ElicModel, inference
     from .scorenet import build_score_network
 
+    resolve_policy(args, log=lambda m: print(m, flush=True))
     cfg, raw = C.load_config(args.config, args.config_mod)
     if args.subsample is not None:
         cfg.sampling.subsample = args.subsample
@@ -199,6 +256,7 @@ def main(argv=None):
                     with open(path, "rb") as fh:          # refuses a stream coded under another arithmetic
                         d_rx, keys_rx, shape_rx = container.unpack(fh.read(), expect_codec=model.codec_tag())
                 frames = dec.decode(d_rx, keys_rx, shape_rx, generator=gen)[..., :gt.shape[-2], :gt.shape[-1]]
+                check_numerics(frames, f"videos {chunk[0]}..{chunk[-1]} q{q}")
                 x_all = frames.cpu().numpy()
                 for j, vid in enumerate(chunk):
                     bits = [count_bits([[[[p[j]] for p in sl] for sl in k[0]], [k[1][j]]]) for k in keys]
@@ -216,6 +274,7 @@ def main(argv=None):
         for vid in vids:
             for q in args.q:
                 for r in res[(vid, q)]:
+                    check_numerics(r["x"], f"video {vid} q{q} thr {r['thr']:.2f}")
                     report(vid, q, r["thr"], r["x"], clips[vid].numpy(), r["bits"], r["d"], store)
                     if args.policy == "lpips":      # per-frame distances of the decoded clip (city_sender.py:570-571)
                         v = metric.values(torch.from_numpy(r["x"]).to(device), clips[vid].to(device))

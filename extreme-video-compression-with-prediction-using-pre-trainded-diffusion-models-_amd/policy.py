@@ -18,6 +18,7 @@ threshold): LPIPS needs torchvision's pretrained AlexNet, which cannot be fetche
 by the user (``--policy lpips --metric pkg.module:function`` or the ``lpips`` package when it is importable).
 """
 import importlib
+import os
 
 import numpy as np
 import torch
@@ -70,7 +71,8 @@ def load_metric(policy, spec=None, device="cuda"):
         return PsnrMetric()
     if policy != "lpips":
         raise ValueError(f"unknown policy metric {policy!r}")
-    if spec and ".pt" in spec:
+    if spec and (spec.startswith("file:") or all(os.path.isfile(part) for part in spec.split(","))):
+        spec = spec[5:] if spec.startswith("file:") else spec
         # weight files: "alexnet-owt-*.pth,alex.pth" (torchvision backbone + lpips v0.1 linear layers) or one file holding
         # a saved lpips.LPIPS state dict -> the HIP implementation (lpips.py); frames are passed as they are, like the reference
         from .lpips import LpipsAlex

@@ -488,35 +488,46 @@ class ScoreNet(DdpmWrapper):
                     self._bounds = self._bounds_by_stream[key] = torch.empty(256, device=self.device, dtype=torch.int32)
             self._bounds.zero_()          # one memset per forward; slots are handed out in program order
             self._bound_next = 0
+        # test hook (tests/test_gpu_scorenet.py): ``self.taps = {}`` before a call collects every module's output, NCHW,
+        # under its index in the reference's ``all_modules`` list (ncsnpp_more.py:251-392)
+        taps = getattr(self, "taps", None)
+
+        def tap(idx, act):
+            if taps is not None:
+                taps[idx] = act.t[..., :prog[idx].get("cout", prog[idx].get("ch"))].permute(0, 3, 1, 2).contiguous()
+            return act
         i = 2
         m = prog[i]
         xin = self._pack_input(x, cond, self.w[i]["cin_pad"])
-        hs = [_Act(*L.conv2d_nhwc(xin, self.w[i]["w"], m["cout"], 3, 3, bias=self.w[i]["b"], want_stats=True))]
+        hs = [tap(i, _Act(*L.conv2d_nhwc(xin, self.w[i]["w"], m["cout"], 3, 3, bias=self.w[i]["b"], want_stats=True)))]
         i += 1
         n_lvl = len(d.ch_mult)
         for lvl in range(n_lvl):
             for _ in range(d.num_res_blocks):
-                h = self._res(i, prog[i], hs[-1], None, rows); i += 1
+                h = tap(i, self._res(i, prog[i], hs[-1], None, rows)); i += 1
                 if h.t.shape[2] in d.attn_resolutions:
-                    h = self._attn(i, prog[i], h); i += 1
+                    h = tap(i, self._attn(i, prog[i], h)); i += 1
                 hs.append(h)
             if lvl != n_lvl - 1:
-                hs.append(self._res(i, prog[i], hs[-1], None, rows)); i += 1
+                hs.append(tap(i, self._res(i, prog[i], hs[-1], None, rows))); i += 1
         h = hs[-1]
-        h = self._res(i, prog[i], h, None, rows); i += 1
-        h = self._attn(i, prog[i], h); i += 1
-        h = self._res(i, prog[i], h, None, rows); i += 1
+        h = tap(i, self._res(i, prog[i], h, None, rows)); i += 1
+        h = tap(i, self._attn(i, prog[i], h)); i += 1
+        h = tap(i, self._res(i, prog[i], h, None, rows)); i += 1
         for lvl in reversed(range(n_lvl)):
             for _ in range(d.num_res_blocks + 1):
-                h = self._res(i, prog[i], h, hs.pop(), rows); i += 1
+                h = tap(i, self._res(i, prog[i], h, hs.pop(), rows)); i += 1
             if h.t.shape[2] in d.attn_resolutions:
-                h = self._attn(i, prog[i], h); i += 1
+                h = tap(i, self._attn(i, prog[i], h)); i += 1
             if lvl != 0:
-                h = self._res(i, prog[i], h, None, rows); i += 1
+                h = tap(i, self._res(i, prog[i], h, None, rows)); i += 1
         assert not hs
         out, co = self._final(i, h)
         assert i + 2 == len(prog)
-        return L.nhwc_to_nchw(out, co)
+        res = L.nhwc_to_nchw(out, co)
+        if taps is not None:
+            taps[i + 1] = res
+        return res
 
     def _pack_input(self, x, cond, cin_pad):
         """Network input: frames to denoise and conditioning frames concatenated along channels (ncsnpp_more.py:256-257)."""

@@ -44,6 +44,17 @@ class SpadeScoreNet(ScoreNet):
         self.overlap_skip = False
 
     # ---- parameters ----------------------------------------------------------------------------
+    def _pack_conv(self, w, pad_ci=None, bounded=False):
+        """Every 3x3 convolution of this network (Conv_0, Conv_1, the output convolution, the map convolutions) reads a
+        MATERIALISED tensor -- the SPADE act-norm output, norm(x) (1 + gamma_map) + beta_map then scale / shift / SiLU, or
+        resized conditioning frames -- whose range no coefficient kernel has bounded (gn_coeffs runs in mode 0 here and
+        sees only the unmodulated norm(x); evc_spade_act raises no range event).  The fp16 split's "range_events == 0 proves
+        every operand in range" therefore does not cover them: they stay on the exact bf16 split, which assumes no range.
+        The 1x1 convolutions (skip path with a moments bound, attention projections behind an affine GroupNorm) keep it."""
+        if w.shape[-1] == 3:
+            bounded = False
+        return super()._pack_conv(w, pad_ci, bounded)
+
     def _spade_params(self, name, g):
         """mlp_shared / mlp_gamma / mlp_beta of one MySPADE (layerspp.py:147-150): gamma and beta share their input, so
         their filters are stacked into one convolution whose first half carries the ``1 +`` in its bias."""

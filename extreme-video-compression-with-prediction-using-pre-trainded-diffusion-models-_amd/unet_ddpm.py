@@ -14,10 +14,10 @@ builds this network -- it is the file BASELINE.json names; section 8f item 4).  
   ``nn.Upsample(nearest)`` = ``evc_upfirdn2d_nhwc_f32`` with a 2x2 box kernel, up 2, pad (1, 0);
 * attention = one head of width C (``AttnBlock``, models/unet.py:102-123): Q | K | V ``Nin`` as one 1x1 conv,
   ``evc_attention_f32`` / ``evc_attention_f16x3_f32``, ``OUT`` with the residual.  The attention kernels exist for head
-  widths 32, 64 and 192 only (csrc/attention.hip); this network attends at width 2*ngf (and at the deepest level's width
-  in the middle block), so it runs for ``model.ngf`` in {16, 32, 96} with ``mode: deep`` -- any other width,
-  including the mine.yml value ngf = 192 (attention at 384 channels in ONE head), raises ``NotImplementedError`` from the
-  constructor, before any kernel is launched.
+  widths 32, 64, 128, 192 and 256 (``ATTENTION_WIDTHS`` below, csrc/attention.hip); this network attends at width 2*ngf
+  (and at the deepest level's width in the middle block), so it runs for ``model.ngf`` in {16, 32, 64, 96, 128} with
+  ``mode: deep`` -- any other width, including the mine.yml value ngf = 192 (attention at 384 channels in ONE head), raises
+  ``NotImplementedError`` from the constructor, before any kernel is launched.
 """
 import math
 

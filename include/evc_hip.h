@@ -33,7 +33,8 @@ extern "C" {
 #define EVC_ARITH_F32 0
 #define EVC_ARITH_BF16X6 1
 /*   EVC_ARITH_F16X3   both operands are scaled by powers of two into fp16's range (weights per tensor at pack time,
- *                     activations by 8 with saturation at +-65504), split 2-way into fp16 (11 + 11 significand bits,
+ *                     activations by 8 -- nothing is clamped: an element beyond fp16's range comes out as NaN and the
+ *                     EVC_RANGE_* word below says beforehand whether one can exist), split 2-way into fp16 (11 + 11 significand bits,
  *                     2^-22 relative) and three cross products run on v_mfma_f32_32x32x16_f16 (bf16 rate); the exact
  *                     inverse scale is applied to the fp32 accumulator.  Half the MFMAs and two thirds of the LDS
  *                     bytes of BF16X6.  Measured error against fp64: BELOW both F32 and BF16X6 for O(1) operands

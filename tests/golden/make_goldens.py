@@ -350,6 +350,20 @@ def gen_traj_fpndm_full():
          stats=torch.stack([o.mean(), o.std(), o.abs().max()]))
 
 
+def gen_traj_ddim_full():
+    """Full-size 5-step DDIM trajectory (5 deterministic steps + the denoise call = 6 reference forwards), B=2.
+    Reference: models/__init__.py:103-204."""
+    from models import ddim_sampler
+    torch.set_num_threads(8)
+    net, d = ref_net(192, 192, 128, 1234)
+    x_T, cond = rnd(831, 2, 15, 128, 128), rnd(832, 2, 6, 128, 128)
+    out = ddim_sampler(x_T.clone(), net, cond=cond, subsample_steps=5, denoise=True, clip_before=True,
+                       final_only=True, t_min=-1, log=True)
+    o = out[0]
+    save("traj_ddim_full", samples=o.reshape(2, -1)[:, ::30].clone(), first_row=o[:, :, 0, :].clone(),
+         stats=torch.stack([o.mean(), o.std(), o.abs().max()]))
+
+
 def gen_unet_ddpm():
     """The reference's alternative score network models/unet.py::UNet_DDPM (reduced: ngf 32, 32x32), with and without
     time conditioning, through its own forward and through the reference DDPM sampler."""
@@ -447,10 +461,10 @@ if __name__ == "__main__":
     gens = dict(schedule=gen_schedule, fir=gen_fir, blocks=gen_blocks, forward_reduced=gen_forward_reduced,
                 samplers=gen_samplers, sampler_options=gen_sampler_options, sampler_gamma=gen_sampler_gamma, model_options=gen_model_options, lpips_lin=gen_lpips_lin,
                 forward_full=gen_forward_full, forward_full_b9=gen_forward_full_b9,
-                traj_full=gen_traj_full, traj_fpndm_full=gen_traj_fpndm_full, unet_ddpm=gen_unet_ddpm, forward_spade=gen_forward_spade)
+                traj_full=gen_traj_full, traj_fpndm_full=gen_traj_fpndm_full, traj_ddim_full=gen_traj_ddim_full, unet_ddpm=gen_unet_ddpm, forward_spade=gen_forward_spade)
     for name, fn in gens.items():
         if a.only and name != a.only:
             continue
-        if a.skip_full and name in ("forward_full", "forward_full_b9", "traj_full", "traj_fpndm_full"):
+        if a.skip_full and name in ("forward_full", "forward_full_b9", "traj_full", "traj_fpndm_full", "traj_ddim_full"):
             continue
         fn()

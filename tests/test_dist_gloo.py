@@ -89,6 +89,36 @@ def test_bench_gpus2_launches_two_ranks_itself():
     assert line["backend"] == "gloo" and line["broadcast_ok"] is True
 
 
+def test_bench_names_the_stated_multi_gpu_configs_and_their_shards():
+    """BASELINE configs[2] (46 clips block-sharded over the ranks) and configs[4] (256 clips, F-PNDM-50) as bench
+    workloads: 2 gloo ranks print the shard sizes they would decode and the workload name; the weak-scaling default
+    keeps 9 clips on every rank."""
+    rc, line, err = _run_bench(["--gpus", "2", "--plumbing-only", "--total-clips", "46"], {"EVC_DIST_BACKEND": "gloo"})
+    assert rc == 0, err[-2000:]
+    assert line["per_rank_clips"] == [23, 23] and line["scaling"] == "strong"
+    assert line["config"]["workload"].startswith("configs[2]: 46 clips over 2 rank(s) (23,23)")
+    rc, line, err = _run_bench(["--gpus", "2", "--plumbing-only", "--total-clips", "255", "--sampler", "FPNDM",
+                                "--subsample", "50"], {"EVC_DIST_BACKEND": "gloo"})
+    assert rc == 0, err[-2000:]
+    assert line["per_rank_clips"] == [128, 127] and "59 forwards (FPNDM-50)" in line["config"]["workload"]
+    rc, line, err = _run_bench(["--gpus", "2", "--plumbing-only"], {"EVC_DIST_BACKEND": "gloo"})
+    assert rc == 0 and line["per_rank_clips"] == [9, 9] and line["scaling"] == "weak"
+    assert line["config"]["workload"].startswith("configs[1]: 9 clips/GPU")
+    # the plan for the stated 8-rank shapes, without starting 8 processes
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import argparse
+    a = argparse.Namespace(total_clips=46, clips=9, sampler="DDPM", subsample=100)
+    sizes = [bench.rank_clips(a, r, 8)[0] for r in range(8)]
+    assert sizes == [6, 6, 6, 6, 6, 6, 5, 5]
+    assert bench.rank_clips(a, 0, 8)[1].startswith("configs[2]: 46 clips over 8 rank(s) (6,6,6,6,6,6,5,5)")
+    a = argparse.Namespace(total_clips=256, clips=9, sampler="FPNDM", subsample=50)
+    assert [bench.rank_clips(a, r, 8)[0] for r in range(8)] == [32] * 8
+    assert bench.rank_clips(a, 0, 8)[1].startswith("configs[4]: 256 clips over 8 rank(s)")
+
+
 def test_a_failed_rank_ends_the_job_non_zero_in_bounded_time():
     """One rank dies before the first collective: the launcher must come back non-zero (torchrun tears the job down; the
     surviving rank's collective has a bounded wait, EVC_DIST_TIMEOUT_S) -- never a hang, never a result line."""

@@ -71,6 +71,38 @@ def test_cli_keeps_reference_flags():
                                        "--ckpt", "900000", "-p", "a", "b", "--patch", "64", "-c", "ans"])
     assert a.end_idx == 8 and a.paths == ["a", "b"] and a.config == "configs/mine.yml" and a.seed == 1234
     assert a.config_mod == "model.ngf=192 model.n_head_channels=192" and a.exp == "checkpoints/sender"
+    assert a.q == [4, 5] and a.policy is None                      # the reference's sweep; the rule is resolved at run time
+
+
+def test_cli_default_rule_is_the_references_lpips_sweep_when_a_metric_is_available(tmp_path, monkeypatch):
+    """city_sender.py:376-406,504-548: the reference always runs decide_5to5_lpips over thresholds 0.30 ... 0.03 x q in
+    {4, 5}.  The CLI defaults to that rule whenever a perceptual metric is given (--metric) or LPIPS weight files are found
+    where the reference keeps them; `mask` is only the explicit fallback, and the rule that ran is printed."""
+    said = []
+    a = cli.build_parser().parse_args(["--metric", "pkg.mod:fn"])
+    assert cli.resolve_policy(a, log=said.append) == "lpips" and "lpips" in said[-1]
+    # weight files where the reference keeps them: weights/v0.1/alex.pth + torchvision's backbone beside it
+    w = tmp_path / "weights" / "v0.1"
+    w.mkdir(parents=True)
+    (w / "alex.pth").write_bytes(b"x")
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "nohub"))
+    monkeypatch.chdir(tmp_path)
+    assert cli.find_lpips_weights() is None                        # linear layers alone are not a metric
+    (w / "alexnet-owt-7be5be79.pth").write_bytes(b"x")
+    a = cli.build_parser().parse_args([])
+    assert cli.resolve_policy(a, log=said.append) == "lpips"
+    assert a.metric.endswith("alex.pth") and "alexnet-owt-7be5be79.pth" in a.metric
+    # nothing available: the explicit fallback, said out loud
+    (w / "alexnet-owt-7be5be79.pth").unlink()
+    a = cli.build_parser().parse_args([])
+    assert cli.resolve_policy(a, log=said.append) == "mask" and "fallback" in said[-1]
+    # an explicit --policy always wins
+    a = cli.build_parser().parse_args(["--policy", "psnr"])
+    assert cli.resolve_policy(a, log=said.append) == "psnr"
+    # the thresholds of the reference's sweep (city_sender.py:508)
+    import numpy as np
+    thr = [float("%.2f" % t) for t in np.arange(0.30, 0.02, -0.01)]
+    assert len(thr) == 28 and thr[0] == 0.30 and thr[-1] == 0.03
 
 
 def test_compute_path_fails_loudly_without_gpu():
