@@ -159,6 +159,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int mb = mw + i * 32;
+                if (TM == 4 && i == 2) {
+                    // 128-pixel wave tiles (wide kernel): the moments go out in 64-pixel runs, the layout of the split-K combine
+                    // kernel, so that a K-split tail may mix both producers
+                    if (!partial && p.stats) {
+                        st_sum += __shfl_xor(st_sum, 32);
+                        st_sq += __shfl_xor(st_sq, 32);
+                        if (half == 0) {
+                            float* sp = p.stats + ((size_t)(m0 / 64 + wm * 2) * p.Co + co) * 2;
+                            sp[0] = st_sum; sp[1] = st_sq;
+                        }
+                    }
+                    st_sum = 0.f; st_sq = 0.f;
+                }
                 if (partial) {
                     float* o = p.ws + ((size_t)split * ws_M + (mb - ws_m0)) * p.Co + co;
 #pragma unroll
@@ -187,7 +200,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
                 st_sum += __shfl_xor(st_sum, 32);
                 st_sq += __shfl_xor(st_sq, 32);
                 if (half == 0) {
-                    float* sp = p.stats + ((size_t)(m0 / (32 * TM) + wm) * p.Co + co) * 2;
+                    float* sp = p.stats + (TM == 4 ? (size_t)(m0 / 64 + wm * 2 + 1) : (size_t)(m0 / (32 * TM) + wm)) * p.Co * 2 + (size_t)co * 2;
                     sp[0] = st_sum; sp[1] = st_sq;
                 }
             }
@@ -1212,6 +1225,386 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kerne
     conv_epilogue<TM, TN, WM>(p, acc, m0, n0, split, wm, wn, l31, half, tail);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wide-tile form of the f16x3 3x3 convolution (round 4): 256 pixels x 192 channels per workgroup, ONE 4-wave workgroup per
+// CU (one wave per SIMD, so each wave may use up to 512 VGPRs), wave tile 128 pixels x 96 channels = 4 x 3 accumulator tiles.
+//
+// What the row-reuse kernel's counters said (profiles/NOTES.md round 3): per MFMA it issues too much non-MFMA work -- 20
+// fragment reads per 36 MFMAs, a 12 KB weight slab by LDS-DMA per 72 MFMAs per workgroup (125-226 cycles to ISSUE each
+// 1 KB piece beside a busy matrix pipe), every input row gathered + GroupNorm/SiLU-transformed + split three times (once
+// by each of the three tiles that need it).  Here:
+//   * wave tile 128 x 96: 8 activation fragment reads per 36 MFMAs, and the weights do not touch the LDS at all -- a lane's B
+//     fragment is 16 contiguous bytes of the packed weights ([tap][chunk][plane][co][16 fp16], halves pre-swizzled), so each
+//     wave loads its own 6 fragments per K-step straight from L2 into registers (global_load_dwordx4, one fully coalesced
+//     1 KB block per instruction), prefetched TWO K-steps ahead in a 3-deep register rotation: no LDS-DMA issue cost, no
+//     weight barrier, no LDS bandwidth for half of the operand traffic;
+//   * a macro-step is a whole 16-channel chunk: the tile's 256 / W image rows plus one halo row above and below are staged
+//     ONCE (zero halo pixel left and right of each row) and all NINE taps read their A fragments from that image at
+//     offsets ty * (W + 2) + tx -- an input row is gathered, transformed and split (R + 2) / R times instead of 3
+//     (2x at 128 x 128, 1.5x at 64 x 64, 1.25x at 32 x 32), activation loads and LDS writes likewise;
+//   * ONE workgroup barrier per chunk (324 MFMAs per wave): the next chunk's image is staged into the other LDS buffer
+//     during K-steps 0..7 and published before K-step 8, whose A-fragment prefetch already reads it;
+//   * A fragments are reloaded progressively (the two planes of pixel block i right after its 9 MFMAs were issued), B
+//     fragments rotate through three register sets; with 192 accumulator registers that is ~400 VGPRs.
+// Same operand arithmetic, same fused epilogue (bias, residual, scale, activation, moments in 64-pixel runs), same fused
+// 1x1 operand, same K-split tail / split-K slabs as conv_split_rr_kernel; results differ from it by fp32 summation order
+// only (taps inner instead of channel chunks inner per kernel row).
+// Requires: f16x3, 3x3, Co % 192 == 0, H*W % 256 == 0, 256 % W == 0 (tiles = whole rows of ONE image).
+#ifndef EVC_WIDE_VMEM_EVERY
+#define EVC_WIDE_VMEM_EVERY 36  // one global load (weight fragment / staging) issued per this many MFMAs: 64 B/clk of L1 path per CU,
+                                // so a burst of 6-12 loads per wave stalls the wave's MFMA issue behind the other waves' bursts
+#endif
+#ifndef EVC_WIDE_BDIST
+#define EVC_WIDE_BDIST 1        // weight fragments are fetched this many K-steps ahead (1 or 2; three register sets either way)
+#endif
+#ifndef EVC_WIDE_ABL
+#define EVC_WIDE_ABL 0     // diagnostic builds of tools/conv_bench.hip only (WRONG results): 1 = no staging arithmetic, 2 = no weight loads in
+                           // the loop, 4 = no fragment reads in the loop, 8 = no activation loads in the loop, 16 = no epilogue
+#endif
+template <int MODE, int NU>
+__global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
+    typedef Split<2> SP;
+    typedef f16x8 vec;
+    constexpr int TM = 4, TN = 3, BM = 256, BN = 192, RB = 32;
+    constexpr bool HAS_COEF = MODE == MODE_AFFINE || MODE == MODE_AFFINE_SILU;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    const int W = p.W, SW = W + 2;
+    const int R = BM / W;                              // image rows per tile
+    const int SPX = (R + 2) * SW;                      // staged pixels: R + 2 rows of W + 2
+    const int APL = SPX * RB;                          // bytes per activation plane
+    // LDS image: [2 buffers][2 planes][2 channel halves][SPX pixels][16 B].  The two 8-channel halves of a pixel live in
+    // separate regions, so the 16 lanes of a ds_read_b128 group (one half, 16 pixels with gaps of 8 / 4) read 16-byte pieces
+    // 16 bytes apart: bank-conflict free under ANY tap shift with no XOR swizzle -- a fragment address is one per-lane base
+    // plus a wave-uniform tap offset.
+    const int HPL = SPX * 16;                          // bytes per channel half of a plane
+    char* const As = smem_b;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // K-split tail (ConvK::tail_*): blockIdx.x beyond the unsplit tiles enumerates (tile, split) pairs of the last tiles
+    const bool tail = (int)blockIdx.x >= p.tail_first;
+    const int tq = tail ? ((int)blockIdx.x - p.tail_first) / p.tail_splits : 0;
+    const int m0 = (tail ? p.tail_first + tq : (int)blockIdx.x) * BM;
+    const int n0 = blockIdx.y * BN;
+    const int split = tail ? (int)blockIdx.x - p.tail_first - tq * p.tail_splits : (int)blockIdx.z;
+    const int sps = tail ? p.tail_sps : p.steps_per_split;                      // multiple of 9 (host)
+    const int c_begin = min(p.nchunk, split * (sps / 9));
+    const int c_end = min(p.nchunk, c_begin + sps / 9);
+
+    const int bimg = m0 / p.HW;                        // the tile lies inside ONE image (HW % 256 == 0)
+    const int y0 = (m0 - bimg * p.HW) / W;
+    const int Ct = p.C0 + p.C1;
+
+    // ---- staging units of this thread: (staged row, column, 8-channel half); unit u = tid + 256 k ----
+    const int kh = tid & 1;
+    unsigned goff0[NU], goff1[NU];
+    int slds[NU];
+    bool sval[NU], sex[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        int pp = (tid + 256 * k) >> 1;
+        if (pp >= (R + 2) * W) pp = tid >> 1;          // surplus unit (W < 128): repeats this thread's unit 0 -- same bytes to
+                                                       // the same place, which keeps the K-step free of branches
+        const int sr = pp / W, x = pp - sr * W;
+        sex[k] = true;
+        const int y = y0 + sr - 1;
+        sval[k] = sex[k] && y >= 0 && y < p.H;
+        const unsigned pix = (unsigned)((bimg * p.H + (sval[k] ? y : 0)) * W + x);        // row 0 of the image: always legal
+        goff0[k] = (pix * (unsigned)p.ld0 + 8u * kh) * 4u;
+        goff1[k] = (pix * (unsigned)p.ld1 + 8u * kh) * 4u;
+        const int spx = (sex[k] ? sr : 0) * SW + x + 1;
+        slds[k] = kh * HPL + spx * 16;
+    }
+    // ---- A fragment offsets: output pixel ml of the tile at tap (ty, tx) sits at staged pixel (r + ty) * SW + x + tx ----
+    int abase[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = wm * 128 + i * 32 + l31;
+        const int r = ml / W, x = ml - r * W;
+        abase[i] = half * HPL + (r * SW + x) * 16;
+    }
+    const auto tap_off = [&](int t) { return ((t / 3) * SW + (t % 3)) * 16; };       // wave-uniform
+    // ---- B fragment: 16 bytes per lane of the packed weights, read straight from global memory ----
+    const unsigned planeB = (unsigned)p.CoPad * RB;                       // bytes per plane of a (tap, chunk) slab
+    const unsigned slab = 2u * planeB;
+    const unsigned w_tap = (unsigned)p.nchunk * slab;
+    const unsigned wlane = (unsigned)(n0 + wn * 96 + l31) * RB + 16u * (unsigned)(half ^ ((l31 >> 3) & 1));
+    const char* const wbase = reinterpret_cast<const char*>(p.w);
+    auto load_b = [&](vec (&bb)[TN][2], int c, int t) {
+        const char* wt = wbase + ((unsigned)t * w_tap + (unsigned)c * slab);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bb[j][0] = *reinterpret_cast<const vec*>(wt + wlane + j * 32 * RB);
+            bb[j][1] = *reinterpret_cast<const vec*>(wt + planeB + wlane + j * 32 * RB);
+        }
+    };
+
+    const float xscale = F16_ACT_SCALE * in_scale(p);
+    float4 xr[NU][2], ca[2], cs[2];
+    vec a[TM][2];
+    auto stage_load = [&](int k, int c) {               // activation registers of staging unit k, chunk c
+        const int cc = c * KC;
+        const bool first = cc < p.C0;                   // wave-uniform
+        const char* src = reinterpret_cast<const char*>(first ? p.src0 : p.src1);
+        const unsigned o = (first ? goff0[k] : goff1[k]) + (unsigned)(first ? cc : cc - p.C0) * 4u;
+        xr[k][0] = *reinterpret_cast<const float4*>(src + o);
+        xr[k][1] = *reinterpret_cast<const float4*>(src + o + 16);
+    };
+    auto coef_load = [&](int c) {                       // GroupNorm coefficients of chunk c (this thread's 8 channels)
+        if (HAS_COEF) {
+            const size_t co = (size_t)bimg * Ct + c * KC + 8 * kh;
+            ca[0] = *reinterpret_cast<const float4*>(p.coef_a + co);
+            ca[1] = *reinterpret_cast<const float4*>(p.coef_a + co + 4);
+            cs[0] = *reinterpret_cast<const float4*>(p.coef_s + co);
+            cs[1] = *reinterpret_cast<const float4*>(p.coef_s + co + 4);
+        }
+    };
+    auto stage_store = [&](int k, int buf) {            // transform + split + LDS write of staging unit k
+        vec pl[2];
+        SP::split(transform<MODE>(xr[k][0], ca[0], cs[0], sval[k]), transform<MODE>(xr[k][1], ca[1], cs[1], sval[k]), xscale, pl);
+        char* A = As + buf * 2 * APL + slds[k];
+        *reinterpret_cast<vec*>(A) = pl[0];
+        *reinterpret_cast<vec*>(A + APL) = pl[1];
+    };
+    auto read_a = [&](int i, const char* img, int toff) {       // both planes of pixel block i at a tap offset
+        a[i][0] = *reinterpret_cast<const vec*>(img + abase[i] + toff);
+        a[i][1] = *reinterpret_cast<const vec*>(img + APL + abase[i] + toff);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // zero both activation images once: the halo columns stay zero for the whole kernel
+    for (int o = tid * 16; o < (p.x2_w ? 6 : 4) * APL; o += 256 * 16) *reinterpret_cast<float4*>(As + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+#define EVC_PIN(x) asm volatile("" : "+v"(x))
+#define EVC_PIN4(f) asm volatile("" : "+v"((f).x), "+v"((f).y), "+v"((f).z), "+v"((f).w))
+#define EVC_WIDE_MFMA_I(I, BB)                                                                          \
+    _Pragma("unroll") for (int t_ = 0; t_ < SP::NTERM; ++t_)                                            \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                  \
+            acc[I][j] = SP::mfma(a[I][SP::qa(t_)], BB[j][SP::qb(t_)], acc[I][j]);
+
+    // ---- fused 1x1 operand: out += conv1x1(x2).  One K-step (36 MFMAs per wave) per 16-channel chunk of x2: the tile's own
+    // pixels are staged raw (scaled from x2's element bound) at the centre of the image, fragments read at the centre tap.
+    // Software pipeline over THREE LDS images so that one barrier per chunk is enough and nothing waits behind it: during the
+    // MFMAs of chunk c the fragments of chunk c + 1 are read (image published by the previous barrier), chunk c + 2 is
+    // transformed and written (its loads were issued a chunk earlier) and the loads of chunk c + 3 are issued. ----
+    if (p.x2_w) {
+        const int nch2 = (p.x2_C0 + p.x2_C1) / KC;
+        const int nsp = tail ? p.tail_splits : p.splits;
+        const int per = (nch2 + nsp - 1) / nsp;
+        const int c2b = min(nch2, split * per), c2e = min(nch2, c2b + per);
+        float s2 = 1.0f;
+        {
+            const float bb = sqrtf(__uint_as_float(*p.x2_bound));
+            if (!(bb < 3.0e38f)) s2 = __builtin_nanf("");
+            else if (bb > 0.f) s2 = ldexpf(1.0f, 6 - ilogbf(bb));
+        }
+        const float xscale2 = F16_ACT_SCALE * s2;
+        const unsigned slab2 = 2u * planeB;
+        float4 x2r[2][2];
+        unsigned x2o0[2], x2o1[2];
+        int x2l[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int pp = (tid + 256 * k) >> 1;                       // pixel of the tile
+            const int r = pp / W, x = pp - r * W;
+            x2o0[k] = ((unsigned)(m0 + pp) * (unsigned)p.x2_ld0 + 8u * kh) * 4u;
+            x2o1[k] = ((unsigned)(m0 + pp) * (unsigned)p.x2_ld1 + 8u * kh) * 4u;
+            x2l[k] = kh * HPL + ((r + 1) * SW + x + 1) * 16;
+        }
+        auto load2 = [&](int c) {
+            const int cc = c * KC;
+            const bool first = cc < p.x2_C0;
+            const char* src = reinterpret_cast<const char*>(first ? p.x2_src0 : p.x2_src1);
+            const unsigned cb = (unsigned)(first ? cc : cc - p.x2_C0) * 4u;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const unsigned o = (first ? x2o0[k] : x2o1[k]) + cb;
+                x2r[k][0] = *reinterpret_cast<const float4*>(src + o);
+                x2r[k][1] = *reinterpret_cast<const float4*>(src + o + 16);
+            }
+        };
+        auto store2 = [&](int buf) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                vec pl[2];
+                SP::split(transform<MODE_PLAIN>(x2r[k][0], z, z, true), transform<MODE_PLAIN>(x2r[k][1], z, z, true), xscale2, pl);
+                char* A = As + buf * 2 * APL + x2l[k];
+                *reinterpret_cast<vec*>(A) = pl[0];
+                *reinterpret_cast<vec*>(A + APL) = pl[1];
+            }
+        };
+        vec b2[2][TN][2];
+        auto load_b2 = [&](vec (&bb)[TN][2], int c) {
+            const char* wt = p.x2_w + (unsigned)c * slab2;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bb[j][0] = *reinterpret_cast<const vec*>(wt + wlane + j * 32 * RB);
+                bb[j][1] = *reinterpret_cast<const vec*>(wt + planeB + wlane + j * 32 * RB);
+            }
+        };
+        const int n2 = c2e - c2b;
+        if (n2 > 0) {
+            const auto clampc = [&](int c) { return min(c, c2e - 1); };
+            load2(c2b);
+            load_b2(b2[0], c2b);
+            store2(0);
+            load2(clampc(c2b + 1));
+            store2(1);
+            load2(clampc(c2b + 2));
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TM; ++i) read_a(i, As, tap_off(4));
+            // three images: chunk k of this phase lives in image k % 3 (ring index kept without a division)
+            int ring = 0;
+#define EVC_WIDE_X2_STEP(BCUR, BNXT)                                                                    \
+            {                                                                                           \
+                const int rn1 = ring == 2 ? 0 : ring + 1, rn2 = rn1 == 2 ? 0 : rn1 + 1;                 \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) { EVC_PIN(BCUR[j][0]); EVC_PIN(BCUR[j][1]); } \
+                _Pragma("unroll") for (int k = 0; k < 2; ++k) { EVC_PIN4(x2r[k][0]); EVC_PIN4(x2r[k][1]); } \
+                load_b2(BNXT, clampc(c + 1));                                                           \
+                const char* An = As + rn1 * 2 * APL;                                                    \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                        \
+                    EVC_PIN(a[i][0]); EVC_PIN(a[i][1]);                                                 \
+                    EVC_WIDE_MFMA_I(i, BCUR)                                                            \
+                    read_a(i, An, tap_off(4));                                                          \
+                }                                                                                       \
+                store2(rn2);                                 /* chunk c + 2 */                          \
+                _Pragma("unroll") for (int m = 0; m < 36; ++m) {                                        \
+                    if (m == 0) __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);                      \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
+                    __builtin_amdgcn_sched_group_barrier(0x402, 3, 0);                                  \
+                    if (m % 9 == 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                  \
+                }                                                                                       \
+                __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+                load2(clampc(c + 3));                                                                   \
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                         \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+                ring = rn1;                                                                             \
+            }
+            int c = c2b;
+            for (; c + 1 < c2e; c += 2) {
+                EVC_WIDE_X2_STEP(b2[0], b2[1])
+                ++c;
+                EVC_WIDE_X2_STEP(b2[1], b2[0])
+                --c;
+            }
+            if (c < c2e) EVC_WIDE_X2_STEP(b2[0], b2[1])
+#undef EVC_WIDE_X2_STEP
+        }
+        __syncthreads();
+        // both operands into one accumulator: bring the 1x1 partial sums to the 3x3 operand's scale (power of two: exact)
+        const float r = (p.x2_hdr[0] / s2) / (p.w_hdr[0] / in_scale(p));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] *= r;
+    }
+
+    // ---- main loop over 16-channel chunks; 9 K-steps (taps) per chunk, fully unrolled.  Register budget (256 arch VGPRs
+    // beside the 192 accumulator registers): weights of K-step T + 1 are fetched during K-step T (three named sets, two
+    // live), a staging unit's activation loads are issued two K-steps before its transform + LDS write (two units live). ----
+    vec b[3][TN][2];
+    if (c_begin < c_end) {
+        coef_load(c_begin);
+#pragma unroll
+        for (int k = 0; k < NU; ++k) stage_load(k, c_begin);
+        load_b(b[0], c_begin, 0);
+        if (EVC_WIDE_BDIST == 2) load_b(b[1], c_begin, 1);
+#pragma unroll
+        for (int k = 0; k < NU; ++k) stage_store(k, 0);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) read_a(i, As, 0);
+    }
+    for (int c = c_begin; c < c_end; ++c) {
+        const int ab = (c - c_begin) & 1;
+        const int cn = min(c + 1, c_end - 1);           // the last chunk restages itself into the idle buffer: no branches in the body
+        const char* Acur = As + ab * 2 * APL;
+        const char* Anxt = As + (ab ^ 1) * 2 * APL;
+        // K-step T: MFMAs on b[T % 3] and a; fetches b[(T + 1) % 3] (weights of K-step T + 1); after the 9 MFMAs of pixel
+        // block i its fragments of K-step T + 1 are read; LOADK / STOREK: staging unit whose loads are issued / whose
+        // transform + split + LDS write happens in this K-step (-1 = none)
+        // hipcc linearises pure instructions (MFMAs, the staging arithmetic) wherever their operands are ready, across
+        // sched_barrier: each K-step therefore first "pins" the values it consumes (empty volatile asm that redefines them),
+        // which keeps a K-step's MFMAs and its staging unit's arithmetic inside the K-step
+#define EVC_WIDE_STEP(T, LOADK, STOREK, TAIL_CODE)                                                      \
+        {                                                                                               \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) { EVC_PIN(b[T % 3][j][0]); EVC_PIN(b[T % 3][j][1]); } \
+            if constexpr (STOREK >= 0 && STOREK < NU) { EVC_PIN4(xr[STOREK < 0 ? 0 : STOREK][0]); EVC_PIN4(xr[STOREK < 0 ? 0 : STOREK][1]); } \
+            if constexpr (STOREK == 0 && HAS_COEF) { EVC_PIN4(ca[0]); EVC_PIN4(ca[1]); EVC_PIN4(cs[0]); EVC_PIN4(cs[1]); } \
+            if (!(EVC_WIDE_ABL & 2)) load_b(b[(T + EVC_WIDE_BDIST) % 3], (T + EVC_WIDE_BDIST < 9) ? c : cn, (T + EVC_WIDE_BDIST) % 9); \
+            if (T == 0 && !(EVC_WIDE_ABL & 8)) coef_load(cn);                                           \
+            if constexpr (LOADK >= 0 && LOADK < NU && !(EVC_WIDE_ABL & 8)) stage_load(LOADK < 0 ? 0 : LOADK, cn); \
+            const char* An = (T == 8) ? Anxt : Acur;                /* image holding K-step T + 1 */    \
+            const int toff = tap_off((T + 1) % 9);                                                      \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                            \
+                EVC_PIN(a[i][0]); EVC_PIN(a[i][1]);                                                     \
+                EVC_WIDE_MFMA_I(i, b[T % 3])                                                            \
+                if (!(EVC_WIDE_ABL & 4)) read_a(i, An, toff);                                           \
+            }                                                                                           \
+            if constexpr (STOREK >= 0 && STOREK < NU && !(EVC_WIDE_ABL & 1)) stage_store(STOREK < 0 ? 0 : STOREK, ab ^ 1); \
+            /* issue order: one global load per EVC_WIDE_VMEM_EVERY MFMAs, the staging arithmetic in the MFMAs' shadow */ \
+            /* (<= 4 vector instructions each), a pixel block's two fragment reads behind its 9 MFMAs                  */ \
+            _Pragma("unroll") for (int m = 0; m < 36; ++m) {                                            \
+                if (m % EVC_WIDE_VMEM_EVERY == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      \
+                __builtin_amdgcn_sched_group_barrier(0x402, 4, 0);                                      \
+                if (m % 9 == 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                      \
+            }                                                                                           \
+            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+            TAIL_CODE                                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+        }
+        // (the GroupNorm coefficients of the chunk being staged are loaded in K-step 0: the previous chunk's were last used in
+        // the previous iteration's K-step 5)
+        EVC_WIDE_STEP(0, 0, -1, )
+        EVC_WIDE_STEP(1, 1, -1, )
+        EVC_WIDE_STEP(2, 2, 0, )
+        EVC_WIDE_STEP(3, 3, 1, )
+        EVC_WIDE_STEP(4, -1, 2, )
+        EVC_WIDE_STEP(5, -1, 3, )
+        EVC_WIDE_STEP(6, -1, -1, )
+        // K-step 7 ends with the chunk's only barrier: every wave has read its K-step 8 fragments from the current image
+        // and written its share of the next one
+        EVC_WIDE_STEP(7, -1, -1, asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");)
+        EVC_WIDE_STEP(8, -1, -1, )
+#undef EVC_WIDE_STEP
+    }
+#undef EVC_WIDE_MFMA_I
+#undef EVC_PIN
+#undef EVC_PIN4
+
+    if (EVC_WIDE_ABL & 16) {        // diagnostic: keep the accumulators alive with one store per lane
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sacc += acc[i][j][e];
+        p.out[(size_t)m0 * p.ld_out + tid] = sacc;
+        return;
+    }
+    conv_epilogue<TM, TN, 2>(p, acc, m0, n0, split, wm, wn, l31, half, tail);
+}
+
 // out = act((sum_z ws[z] + bias + res) * scale): deterministic split-K combine.
 // Block = one 64-pixel run x 64 channels, 1024 threads (thread: channel tid & 63, rows tid >> 6, +16, ...):
 // 256-byte coalesced rows, 4 rows per thread so even the 8x8 layers (M = 64 B) expose enough loads in flight,
@@ -1440,11 +1833,12 @@ static int conv_validate(const evc_conv_args* a) {
 // of 128 pixels: the 8x8 layers) use the 64-pixel tile (TM = 1) first: half the split factor means half the slab
 // write + combine traffic and no half-empty tiles (A/B: 8x8 768->768 58 -> 69 TFLOP/s; on mid-size grids such
 // as 32x32 576->576 the smaller tile loses, 92 -> 84, so it is not used there).
-struct TileCfg { int tm, tn, bm, bn; long long tiles; int splits; int reuse; int steps_per_split;
+struct TileCfg { int tm, tn, bm, bn; long long tiles; int splits; int reuse; int wide; int steps_per_split;
                  int tail_first, tail_tiles, tail_splits, tail_sps; };    // K-split tail: pixel tiles >= tail_first (0 tiles = none)
 static int g_tail_split = EVC_CONV_TAIL;   // run-time option "tail_split"
 static int g_wide_tiles = EVC_SPLIT_WIDE_TILES;   // harness A/B switch for the 256-pixel row-reuse tiles
 static int g_no_reuse = 0;     // same: lets the harness A/B the row-reuse kernel inside one binary
+static int g_wide256 = 1;      // run-time option "wide256": the 256 x 192 one-workgroup-per-CU kernel (conv_wide_kernel) on grids of >= 1 round
 static int g_force_tm = 0;     // tools/conv_bench.hip (same translation unit) sets this to sweep tile heights; never set in the library
 
 // Tile height and split-K factor of the split-arithmetic kernels: 2 workgroups per CU = 512 slots.  Every candidate
@@ -1532,8 +1926,19 @@ static long long rr_lds_bytes(int np, int bm, int W, int bn) {
     return (long long)np * 32 * (2LL * (bm / W) * (W + 2) + 2LL * bn);
 }
 
+// dynamic LDS of the wide kernel: 2 images (3 when a fused 1x1 operand is pipelined through them) x 2 planes x
+// (256 / W + 2) rows of W + 2 pixels x 32 B
+static long long wide_lds_bytes(int W, bool x2) { return (x2 ? 6LL : 4LL) * (256 / W + 2) * (W + 2) * 32; }
+
+// conv_wide_kernel: f16x3, 3x3, 192-channel output tiles, 256-pixel tiles made of whole rows of one image
+static bool wide_ok(const evc_conv_args* a) {
+    return g_wide256 && a->arith == EVC_ARITH_F16X3 && a->KH == 3 && a->KW == 3 && a->Co % 192 == 0 &&
+           (a->W == 16 || a->W == 32 || a->W == 64 || a->W == 128) && ((long long)a->H * a->W) % 256 == 0;
+}
+
 static TileCfg conv_tile_cfg(const evc_conv_args* a) {
     TileCfg c;
+    c.wide = 0;
     const long long M = (long long)a->B * a->H * a->W;
     const int CoPad = evc_conv_co_pad(a->Co);
     c.tn = pick_tn(CoPad);
@@ -1575,6 +1980,30 @@ static TileCfg conv_tile_cfg(const evc_conv_args* a) {
         }
         c.splits = (int)splits;
     }
+    // Wide kernel (one 256 x 192 workgroup per CU = 256 slots per round): grids that offer at least one full round.  R full
+    // rounds of unsplit tiles, then the pixel tiles of the partial round split along K (whole 16-channel chunks, >= 3 per
+    // workgroup) so that they fill the machine once more -- the K-split tail of the row-reuse kernel with 256 slots.
+    if (wide_ok(a) && a->splits <= 0 && !g_force_tm) {
+        const long long tm_all = M / 256, nt = a->Co / 192, wgs = tm_all * nt;
+        if (wgs >= 256) {
+            const int nchunk = (a->C0 + a->C1) / KC;
+            c.wide = 1; c.reuse = 0; c.tm = 4; c.tn = 3; c.bm = 256; c.bn = 192; c.tiles = wgs; c.splits = 1;
+            c.tail_first = 0; c.tail_tiles = 0; c.tail_splits = 1; c.tail_sps = 0;
+            const long long Rr = wgs / 256;
+            const long long main_m = Rr * 256 / nt, tail_m = tm_all - main_m;
+            if (g_tail_split && tail_m > 0) {
+                int ts = (int)(256 / (tail_m * nt));
+                if (ts > nchunk / 3) ts = nchunk / 3;
+                if (ts >= 2) {
+                    const int cps = (nchunk + ts - 1) / ts;               // chunks per tail workgroup
+                    ts = (nchunk + cps - 1) / cps;
+                    c.tail_first = (int)main_m; c.tail_tiles = (int)tail_m; c.tail_splits = ts; c.tail_sps = cps * 9;
+                }
+            }
+            c.steps_per_split = nsteps;
+            return c;
+        }
+    }
     // splits of the row-reuse kernel cover whole (chunk, kernel row) groups: 3 taps
     const int unit = c.reuse ? a->KW : 1;
     int sps = (nsteps + c.splits - 1) / c.splits;
@@ -1590,6 +2019,7 @@ extern "C" int evc_conv_set_option(const char* name, int value) {
     if (is("wide_tiles")) { g_wide_tiles = value; return EVC_OK; }
     if (is("row_reuse")) { g_no_reuse = !value; return EVC_OK; }
     if (is("tail_split")) { g_tail_split = value; return EVC_OK; }
+    if (is("wide256")) { g_wide256 = value; return EVC_OK; }
     return EVC_EINVAL;
 }
 
@@ -1597,7 +2027,8 @@ extern "C" int evc_conv_set_option(const char* name, int value) {
 extern "C" int evc_conv_fused_1x1_supported(const evc_conv_args* a) {
     if (conv_validate(a) != EVC_OK) return 0;
     if (a->arith != EVC_ARITH_F16X3 || a->KH != 3 || a->KW != 3) return 0;
-    return conv_tile_cfg(a).reuse == 1 ? 1 : 0;
+    const TileCfg c = conv_tile_cfg(a);
+    return (c.reuse == 1 || c.wide) ? 1 : 0;
 }
 
 extern "C" int evc_conv_choose_splits(const evc_conv_args* a) {
@@ -1610,7 +2041,7 @@ extern "C" int evc_conv_stats_splits(const evc_conv_args* a) {
     const int HW = a->H * a->W;
     if (HW % 64 != 0) return 0;
     const TileCfg c = conv_tile_cfg(a);
-    if (c.splits > 1) return HW / 64;                          // produced by the split-K combine kernel (64-pixel runs)
+    if (c.splits > 1 || c.wide) return HW / 64;                // split-K combine kernel / wide kernel's epilogue: 64-pixel runs
     // (a K-split tail mixes both producers: the epilogue of the unsplit tiles and the combine of the tail write the same
     // 64-pixel runs, the checks below hold for it because its tiles are full 128-pixel tiles)
     const long long M = (long long)a->B * HW;
@@ -1622,7 +2053,7 @@ extern "C" int evc_conv_stats_splits(const evc_conv_args* a) {
 extern "C" long long evc_conv_workspace_bytes(const evc_conv_args* a) {
     if (conv_validate(a) != EVC_OK) return EVC_EINVAL;
     const TileCfg c = conv_tile_cfg(a);
-    if (c.tail_tiles) return (long long)c.tail_splits * c.tail_tiles * 128 * a->Co * (long long)sizeof(float);
+    if (c.tail_tiles) return (long long)c.tail_splits * c.tail_tiles * c.bm * a->Co * (long long)sizeof(float);
     if (c.splits == 1) return 0;
     return (long long)c.splits * a->B * a->H * a->W * a->Co * (long long)sizeof(float);
 }
@@ -1641,6 +2072,9 @@ static int ensure_dynamic_lds(const void* fn, unsigned long long* done_mask, siz
     return EVC_OK;
 }
 
+#ifdef EVC_DEV_FAST     // development builds only (tools/): one load-transform mode instantiated, 5x faster to compile
+#define EVC_MODE_SWITCH(mode, CALL) CALL(MODE_AFFINE_SILU);
+#else
 #define EVC_MODE_SWITCH(mode, CALL)                                   \
     switch (mode) {                                                   \
         case MODE_AFFINE: CALL(MODE_AFFINE); break;                   \
@@ -1649,6 +2083,7 @@ static int ensure_dynamic_lds(const void* fn, unsigned long long* done_mask, siz
         case MODE_RELU: CALL(MODE_RELU); break;                       \
         default: CALL(MODE_PLAIN); break;                             \
     }
+#endif
 
 template <int TM, int TN>
 static int launch_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
@@ -1688,6 +2123,22 @@ template <int NP, int WM, int TN>
 static int launch_split_rr(int mode, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
     int rc = EVC_OK;
 #define EVC_CALL(M) rc = launch_split_rr_one<NP, WM, TN, M>(grid, lds, st, k)
+    EVC_MODE_SWITCH(mode, EVC_CALL)
+#undef EVC_CALL
+    return rc;
+}
+
+template <int MODE, int NU>
+static int launch_wide_one(dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+    static unsigned long long attr_done = 0;
+    const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_wide_kernel<MODE, NU>), &attr_done, lds);
+    if (rc != EVC_OK) return rc;
+    hipLaunchKernelGGL((conv_wide_kernel<MODE, NU>), grid, dim3(256), lds, st, k);
+    return EVC_OK;
+}
+static int launch_wide(int mode, int nu, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+    int rc = EVC_OK;
+#define EVC_CALL(M) rc = nu == 4 ? launch_wide_one<M, 4>(grid, lds, st, k) : launch_wide_one<M, 3>(grid, lds, st, k)
     EVC_MODE_SWITCH(mode, EVC_CALL)
 #undef EVC_CALL
     return rc;
@@ -1755,7 +2206,7 @@ static int conv2d_impl(const evc_conv_args* a, float* ws, void* stream, hipEvent
     k.x2_w = nullptr; k.x2_hdr = nullptr; k.x2_bound = nullptr; k.x2_src0 = k.x2_src1 = nullptr;
     k.x2_C0 = k.x2_C1 = k.x2_ld0 = k.x2_ld1 = 0;
     if (a->x2_w_packed) {
-        if (a->arith != EVC_ARITH_F16X3 || a->KH != 3 || a->KW != 3 || cfg.reuse != 1) return EVC_EUNSUPPORTED;
+        if (a->arith != EVC_ARITH_F16X3 || a->KH != 3 || a->KW != 3 || !(cfg.reuse == 1 || cfg.wide)) return EVC_EUNSUPPORTED;
         k.x2_src0 = a->x2_src0; k.x2_src1 = a->x2_src1 ? a->x2_src1 : a->x2_src0;
         k.x2_C0 = a->x2_C0; k.x2_C1 = a->x2_C1;
         k.x2_ld0 = a->x2_ld0 > 0 ? a->x2_ld0 : a->x2_C0;
@@ -1768,14 +2219,16 @@ static int conv2d_impl(const evc_conv_args* a, float* ws, void* stream, hipEvent
     k.tail_first = 0x7fffffff; k.tail_splits = 1; k.tail_sps = 0; k.tail_rows = 0;
     if (cfg.tail_tiles) {
         k.tail_first = cfg.tail_first; k.tail_splits = cfg.tail_splits; k.tail_sps = cfg.tail_sps;
-        k.tail_rows = cfg.tail_tiles * 128;
+        k.tail_rows = cfg.tail_tiles * cfg.bm;
     }
 
     dim3 grid((k.M + cfg.bm - 1) / cfg.bm, k.CoPad / cfg.bn, k.splits);
     if (cfg.tail_tiles) grid.x = cfg.tail_first + cfg.tail_tiles * cfg.tail_splits;
     hipStream_t st = (hipStream_t)stream;
     if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return EVC_ELAUNCH;
-    if (is_split_arith(a->arith)) {
+    if (cfg.wide) {
+        rc = launch_wide(mode, a->W == 128 ? 4 : 3, grid, (size_t)wide_lds_bytes(a->W, a->x2_w_packed != nullptr), st, k);
+    } else if (is_split_arith(a->arith)) {
         const int np = arith_planes(a->arith);
         if (cfg.reuse) {
             const size_t lds_rr = (size_t)rr_lds_bytes(np, cfg.bm, a->W, cfg.bn);
@@ -1820,7 +2273,7 @@ static int conv2d_impl(const evc_conv_args* a, float* ws, void* stream, hipEvent
         if (hipGetLastError() != hipSuccess) return EVC_ELAUNCH;
     }
     if (cfg.tail_tiles) {       // combine of the tail's rows only
-        const size_t m0 = (size_t)cfg.tail_first * 128;
+        const size_t m0 = (size_t)cfg.tail_first * cfg.bm;
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((k.tail_rows + 63) / 64, (k.Co + 63) / 64), dim3(1024), 0, st, ws,
                            k.tail_splits, k.tail_rows, k.Co, a->bias, a->res ? a->res + m0 * a->ld_res : nullptr, a->ld_res,
                            a->out_scale, a->act_out, a->out + m0 * a->ld_out, a->ld_out,

@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
     const int layout = argc > 1 ? atoi(argv[1]) : 0;
     const int iters = argc > 2 ? atoi(argv[2]) : 10;
     const int only = argc > 3 ? atoi(argv[3]) : -1;
-    const bool skip_f32 = layout == 4 || layout == 5 || layout == 6 || layout == 8;         // layout 5: split arithmetics only (faster A/B)
+    const bool skip_f32 = layout == 4 || layout == 5 || layout == 6 || layout == 7 || layout == 8;         // layout 5: split arithmetics only (faster A/B)
     (void)layout;
     std::vector<Shape> shapes = {{8, 128, 192, 192, 3, 0}, {8, 128, 192, 192, 3, 1}, {9, 128, 192, 192, 3, 1},
                                  {8, 128, 384, 192, 3, 1}, {8, 64, 384, 384, 3, 0}, {8, 64, 384, 384, 3, 1},
@@ -41,6 +41,7 @@ int main(int argc, char** argv) {
     if (layout == 3) g_no_reuse = 1;          // A/B: bf16x6 without the row-reuse kernel
     if (layout == 4) g_wide_tiles = 0;        // A/B: row-reuse kernel with 128-pixel tiles only
     if (layout == 8) g_tail_split = 0;        // A/B: row tiles without the K-split tail
+    if (layout == 7) g_wide256 = 0;           // A/B: without the 256 x 192 one-workgroup-per-CU kernel (round 4)
     printf("# conv_bench layout=%d iters=%d\n", layout, iters);
     if (layout == 2) {
         // sweep of (tile height, split factor) for the mid-size layers under bf16x6: prints the measured table
