@@ -159,19 +159,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int mb = mw + i * 32;
-                if (TM == 4 && i == 2) {
-                    // 128-pixel wave tiles (wide kernel): the moments go out in 64-pixel runs, the layout of the split-K combine
-                    // kernel, so that a K-split tail may mix both producers
-                    if (!partial && p.stats) {
-                        st_sum += __shfl_xor(st_sum, 32);
-                        st_sq += __shfl_xor(st_sq, 32);
-                        if (half == 0) {
-                            float* sp = p.stats + ((size_t)(m0 / 64 + wm * 2) * p.Co + co) * 2;
-                            sp[0] = st_sum; sp[1] = st_sq;
-                        }
-                    }
-                    st_sum = 0.f; st_sq = 0.f;
-                }
                 if (partial) {
                     float* o = p.ws + ((size_t)split * ws_M + (mb - ws_m0)) * p.Co + co;
 #pragma unroll
@@ -200,7 +187,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
                 st_sum += __shfl_xor(st_sum, 32);
                 st_sq += __shfl_xor(st_sq, 32);
                 if (half == 0) {
-                    float* sp = p.stats + (TM == 4 ? (size_t)(m0 / 64 + wm * 2 + 1) : (size_t)(m0 / (32 * TM) + wm)) * p.Co * 2 + (size_t)co * 2;
+                    float* sp = p.stats + ((size_t)(m0 / (32 * TM) + wm) * p.Co + co) * 2;
                     sp[0] = st_sum; sp[1] = st_sq;
                 }
             }
@@ -1225,6 +1212,107 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kerne
     conv_epilogue<TM, TN, WM>(p, acc, m0, n0, split, wm, wn, l31, half, tail);
 }
 
+// Epilogue of conv_wide_kernel (full 256 x 192 tiles only).  A wave owns 128 pixels x 96 channels = 12 accumulator tiles of
+// 32 x 32 in which a lane holds ONE channel of 16 pixels: written as they stand that is 192 four-byte stores per lane, and the
+// store path of a CU is issue-bound (~5 B/clk measured: 19 us per tile, with every CU of a round storing at the same time).
+// Here each tile goes through a wave-private LDS patch [32 pixels][32 channels] (row stride 36 floats) and leaves as 16-byte
+// pieces: one global_store_dwordx4 per 8 pixels x 128 bytes of fully written lines, 48 stores per lane instead of 192.  Two
+// patches per wave alternate, so a tile's read-back overlaps the next tile's arithmetic; a wave's LDS operations execute in
+// order, so no barrier is involved.  Bias, residual, scale, activation and the per-channel moments (64-pixel runs, the
+// layout of the split-K combine kernel, so that a K-split tail may mix both producers) are computed in the accumulator
+// layout, where a lane's 16 values share their channel.  Split-K / tail workgroups write raw partial sums the same way.
+// The wave-uniform cases (partial sums / residual / moments / output activation) are template parameters: with run-time
+// branches inside the 12 unrolled tiles the epilogue was 11 000 lines of tiny basic blocks and took 33 000 cycles per tile.
+template <bool PARTIAL, bool RES, bool STATS, bool ACT>
+__device__ __forceinline__ void wide_epilogue_t(const ConvK& p, f32x16 (&acc)[4][3], char* lds, int m0, int n0, int split,
+                                                int wave, int lane, bool tail) {
+    constexpr int TM = 4, TN = 3, BM = 256, RS = 36;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ws_m0 = tail ? p.tail_first * BM : 0;
+    const size_t ws_M = tail ? (size_t)p.tail_rows : (size_t)p.M;
+    const float ascale = p.w_hdr[0] / in_scale(p);
+    const float oscale = p.out_scale;
+    // (the ACT instantiation is the generic one: residual / moments are then run-time conditions)
+    const bool has_res = RES && (!ACT || p.res != nullptr), has_stats = STATS && (!ACT || p.stats != nullptr);
+    float* const patch0 = reinterpret_cast<float*>(lds) + wave * 2 * 32 * RS;
+    const int wr = lane >> 3, wc = (lane & 7) * 4;                   // read-back: pixel rows wr + 8 k, channels wc .. wc + 3
+    const int mw = m0 + wm * 32 * TM;
+    const int prow = 4 * half * RS + l31;                            // this lane's patch column; row (r & 3) + 8 (r >> 2) added per register
+    // residual: the 4 x 16 bytes per lane of accumulator tile t + 3 are requested before tile t is processed (j-major order)
+    constexpr int RD = 4;                                           // tiles of residual in flight (HBM latency >> one tile's arithmetic)
+    float4 rq[RD][4];
+    const auto res_load = [&](int t, float4 (&dst)[4]) {
+        const int jj = t / TM, ii = t - jj * TM;
+        const float* rp = p.res + (size_t)(mw + ii * 32 + wr) * p.ld_res + n0 + wn * 32 * TN + jj * 32 + wc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = *reinterpret_cast<const float4*>(rp + (size_t)(8 * k) * p.ld_res);
+    };
+    if (has_res) {
+#pragma unroll
+        for (int t = 0; t < RD - 1; ++t) res_load(t, rq[t]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int cj = n0 + wn * 32 * TN + j * 32;
+        const float bias = (!PARTIAL && p.bias) ? p.bias[cj + l31] : 0.f;
+        float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = mw + i * 32;
+            const int tt = j * TM + i;
+            if (has_res && tt + RD - 1 < TM * TN) res_load(tt + RD - 1, rq[(tt + RD - 1) % RD]);
+            // accumulator layout (a lane = one channel): scale + bias, then through the patch
+            float* const P = patch0 + ((i * TN + j) & 1) * 32 * RS;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) P[prow + ((r & 3) + 8 * (r >> 2)) * RS] = acc[i][j][r] * ascale + bias;
+            // read-back layout (a lane = 4 channels of pixel rows wr + 8 k): residual, output scale, activation, moments, store
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float4 q = *reinterpret_cast<const float4*>(P + (wr + 8 * k) * RS + wc);
+                const int m = mb + wr + 8 * k;
+                if (!PARTIAL) {
+                    if (has_res) { const float4& rr = rq[tt % RD][k]; q.x += rr.x; q.y += rr.y; q.z += rr.z; q.w += rr.w; }
+                    q.x *= oscale; q.y *= oscale; q.z *= oscale; q.w *= oscale;
+                    if (ACT) { q.x = act_fn(q.x, p.act_out); q.y = act_fn(q.y, p.act_out); q.z = act_fn(q.z, p.act_out); q.w = act_fn(q.w, p.act_out); }
+                    if (STATS) {
+                        ssum.x += q.x; ssum.y += q.y; ssum.z += q.z; ssum.w += q.w;
+                        ssq.x += q.x * q.x; ssq.y += q.y * q.y; ssq.z += q.z * q.z; ssq.w += q.w * q.w;
+                    }
+                }
+                float* dst = PARTIAL ? p.ws + ((size_t)split * ws_M + (m - ws_m0)) * p.Co + cj + wc
+                                     : p.out + (size_t)m * p.ld_out + cj + wc;
+                *reinterpret_cast<float4*>(dst) = q;
+            }
+            if (has_stats && (i & 1)) {
+                // one 64-pixel run is complete: the 8 lanes with this lane's `wc` (lane distances 8, 16, 32) hold its pixel rows
+#pragma unroll
+                for (int d = 8; d <= 32; d <<= 1) {
+                    ssum.x += __shfl_xor(ssum.x, d); ssum.y += __shfl_xor(ssum.y, d); ssum.z += __shfl_xor(ssum.z, d); ssum.w += __shfl_xor(ssum.w, d);
+                    ssq.x += __shfl_xor(ssq.x, d); ssq.y += __shfl_xor(ssq.y, d); ssq.z += __shfl_xor(ssq.z, d); ssq.w += __shfl_xor(ssq.w, d);
+                }
+                if (wr == 0) {          // lanes 0..7: {sum, sum of squares} of 4 consecutive channels = 32 contiguous bytes
+                    float* sp = p.stats + ((size_t)(m0 / 64 + wm * 2 + (i >> 1)) * p.Co + cj + wc) * 2;
+                    *reinterpret_cast<float4*>(sp) = make_float4(ssum.x, ssq.x, ssum.y, ssq.y);
+                    *reinterpret_cast<float4*>(sp + 4) = make_float4(ssum.z, ssq.z, ssum.w, ssq.w);
+                }
+                ssum = make_float4(0.f, 0.f, 0.f, 0.f); ssq = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void wide_epilogue(const ConvK& p, f32x16 (&acc)[4][3], char* lds, int m0, int n0, int split,
+                                              int wave, int lane, bool tail) {
+    const bool partial = p.splits > 1 || tail;
+    if (partial) wide_epilogue_t<true, false, false, false>(p, acc, lds, m0, n0, split, wave, lane, tail);
+    else if (p.act_out != EVC_ACT_NONE) wide_epilogue_t<false, true, true, true>(p, acc, lds, m0, n0, split, wave, lane, tail);   // rare: generic
+    else if (p.res && p.stats) wide_epilogue_t<false, true, true, false>(p, acc, lds, m0, n0, split, wave, lane, tail);
+    else if (p.stats) wide_epilogue_t<false, false, true, false>(p, acc, lds, m0, n0, split, wave, lane, tail);
+    else if (p.res) wide_epilogue_t<false, true, false, false>(p, acc, lds, m0, n0, split, wave, lane, tail);
+    else wide_epilogue_t<false, false, false, false>(p, acc, lds, m0, n0, split, wave, lane, tail);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Wide-tile form of the f16x3 3x3 convolution (round 4): 256 pixels x 192 channels per workgroup, ONE 4-wave workgroup per
 // CU (one wave per SIMD, so each wave may use up to 512 VGPRs), wave tile 128 pixels x 96 channels = 4 x 3 accumulator tiles.
@@ -1257,11 +1345,20 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_split_rr_kerne
 #ifndef EVC_WIDE_BDIST
 #define EVC_WIDE_BDIST 1        // weight fragments are fetched this many K-steps ahead (1 or 2; three register sets either way)
 #endif
+#ifndef EVC_WIDE_BUFFER_LOADS
+#define EVC_WIDE_BUFFER_LOADS 0
+#endif
 #ifndef EVC_WIDE_ABL
 #define EVC_WIDE_ABL 0     // diagnostic builds of tools/conv_bench.hip only (WRONG results): 1 = no staging arithmetic, 2 = no weight loads in
                            // the loop, 4 = no fragment reads in the loop, 8 = no activation loads in the loop, 16 = no epilogue
 #endif
-template <int MODE, int NU>
+#ifdef EVC_WIDE_STAMPS     // diagnostic builds of tools/conv_bench.hip: s_memtime at the phase boundaries of every workgroup
+__device__ unsigned long long g_wide_stamps[8192 * 8];
+#define EVC_STAMP(k) if (threadIdx.x == 0) g_wide_stamps[(blockIdx.x & 8191) * 8 + (k)] = __builtin_readcyclecounter();
+#else
+#define EVC_STAMP(k)
+#endif
+template <int MODE, int NU, bool X2>
 __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
     typedef Split<2> SP;
     typedef f16x8 vec;
@@ -1285,6 +1382,10 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
 
+#ifdef EVC_WIDE_STAGGER_TEST     // diagnostic: delay the first-round workgroups by (block % 4) x ~4 us so that rounds end out of phase
+    if (blockIdx.x < 256) for (int q = 0; q < (int)((blockIdx.x >> 3) & 3) * EVC_WIDE_STAGGER_TEST; ++q) __builtin_amdgcn_s_sleep(127);
+#endif
+    EVC_STAMP(0)
     // K-split tail (ConvK::tail_*): blockIdx.x beyond the unsplit tiles enumerates (tile, split) pairs of the last tiles
     const bool tail = (int)blockIdx.x >= p.tail_first;
     const int tq = tail ? ((int)blockIdx.x - p.tail_first) / p.tail_splits : 0;
@@ -1334,6 +1435,21 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
     const unsigned w_tap = (unsigned)p.nchunk * slab;
     const unsigned wlane = (unsigned)(n0 + wn * 96 + l31) * RB + 16u * (unsigned)(half ^ ((l31 >> 3) & 1));
     const char* const wbase = reinterpret_cast<const char*>(p.w);
+#if EVC_WIDE_BUFFER_LOADS
+    // buffer form: one wave-uniform descriptor, a 32-bit per-lane offset and a scalar offset per (tap, chunk)
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wbase), 0, 0x7fffffff, 0x00020000);
+    auto load_b = [&](vec (&bb)[TN][2], int c, int t) {
+        const int so = (int)((unsigned)t * w_tap + (unsigned)c * slab);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const i32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane + j * 32 * RB, so, 0);
+            const i32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(wlane + planeB) + j * 32 * RB, so, 0);
+            bb[j][0] = __builtin_bit_cast(vec, q0);
+            bb[j][1] = __builtin_bit_cast(vec, q1);
+        }
+    };
+#else
     auto load_b = [&](vec (&bb)[TN][2], int c, int t) {
         const char* wt = wbase + ((unsigned)t * w_tap + (unsigned)c * slab);
 #pragma unroll
@@ -1342,6 +1458,7 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
             bb[j][1] = *reinterpret_cast<const vec*>(wt + planeB + wlane + j * 32 * RB);
         }
     };
+#endif
 
     const float xscale = F16_ACT_SCALE * in_scale(p);
     float4 xr[NU][2], ca[2], cs[2];
@@ -1383,8 +1500,29 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // zero both activation images once: the halo columns stay zero for the whole kernel
-    for (int o = tid * 16; o < (p.x2_w ? 6 : 4) * APL; o += 256 * 16) *reinterpret_cast<float4*>(As + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the first chunk's operands are requested before anything waits (halo zeroing, barrier): their HBM latency -- every CU of
+    // a round starts at the same time -- then overlaps the rest of the prologue.  (With a fused 1x1 operand that phase comes first.)
+    vec b[3][TN][2];
+    const bool early = !X2 && c_begin < c_end;                      // wave-uniform
+    if (early) {
+        coef_load(c_begin);
+#pragma unroll
+        for (int k = 0; k < NU; ++k) stage_load(k, c_begin);
+        load_b(b[0], c_begin, 0);
+    }
+    EVC_STAMP(5)
+    // zero the halo columns of the activation images once (left / right of every staged row, both channel halves, both
+    // planes): nothing else ever writes them; every other pixel is rewritten by each chunk's staging
+    {
+        const int nimg = X2 ? 3 : 2;
+        const int per_img = (R + 2) * 2 * 4;                         // rows x {left, right} x {plane, half}
+        for (int u = tid; u < nimg * per_img; u += 256) {
+            const int img = u / per_img, q = u - img * per_img;
+            const int ph = q & 3, side = (q >> 2) & 1, row = q >> 3;
+            const int spx = row * SW + (side ? W + 1 : 0);
+            *reinterpret_cast<float4*>(As + img * 2 * APL + (ph >> 1) * APL + (ph & 1) * HPL + spx * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     __syncthreads();
 
 #define EVC_PIN(x) asm volatile("" : "+v"(x))
@@ -1399,7 +1537,7 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
     // Software pipeline over THREE LDS images so that one barrier per chunk is enough and nothing waits behind it: during the
     // MFMAs of chunk c the fragments of chunk c + 1 are read (image published by the previous barrier), chunk c + 2 is
     // transformed and written (its loads were issued a chunk earlier) and the loads of chunk c + 3 are issued. ----
-    if (p.x2_w) {
+    if constexpr (X2) {
         const int nch2 = (p.x2_C0 + p.x2_C1) / KC;
         const int nsp = tail ? p.tail_splits : p.splits;
         const int per = (nch2 + nsp - 1) / nsp;
@@ -1519,19 +1657,23 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
     // ---- main loop over 16-channel chunks; 9 K-steps (taps) per chunk, fully unrolled.  Register budget (256 arch VGPRs
     // beside the 192 accumulator registers): weights of K-step T + 1 are fetched during K-step T (three named sets, two
     // live), a staging unit's activation loads are issued two K-steps before its transform + LDS write (two units live). ----
-    vec b[3][TN][2];
+    EVC_STAMP(6)
     if (c_begin < c_end) {
-        coef_load(c_begin);
+        if (!early) {
+            coef_load(c_begin);
 #pragma unroll
-        for (int k = 0; k < NU; ++k) stage_load(k, c_begin);
-        load_b(b[0], c_begin, 0);
+            for (int k = 0; k < NU; ++k) stage_load(k, c_begin);
+            load_b(b[0], c_begin, 0);
+        }
         if (EVC_WIDE_BDIST == 2) load_b(b[1], c_begin, 1);
 #pragma unroll
         for (int k = 0; k < NU; ++k) stage_store(k, 0);
+        EVC_STAMP(7)
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < TM; ++i) read_a(i, As, 0);
     }
+    EVC_STAMP(1)
     for (int c = c_begin; c < c_end; ++c) {
         const int ab = (c - c_begin) & 1;
         const int cn = min(c + 1, c_end - 1);           // the last chunk restages itself into the idle buffer: no branches in the body
@@ -1548,7 +1690,8 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
             _Pragma("unroll") for (int j = 0; j < TN; ++j) { EVC_PIN(b[T % 3][j][0]); EVC_PIN(b[T % 3][j][1]); } \
             if constexpr (STOREK >= 0 && STOREK < NU) { EVC_PIN4(xr[STOREK < 0 ? 0 : STOREK][0]); EVC_PIN4(xr[STOREK < 0 ? 0 : STOREK][1]); } \
             if constexpr (STOREK == 0 && HAS_COEF) { EVC_PIN4(ca[0]); EVC_PIN4(ca[1]); EVC_PIN4(cs[0]); EVC_PIN4(cs[1]); } \
-            if (!(EVC_WIDE_ABL & 2)) load_b(b[(T + EVC_WIDE_BDIST) % 3], (T + EVC_WIDE_BDIST < 9) ? c : cn, (T + EVC_WIDE_BDIST) % 9); \
+            if (EVC_WIDE_ABL & 64) load_b(b[(T + EVC_WIDE_BDIST) % 3], c_begin, 0);   /* diagnostic: always the same (L1-resident) slab */ \
+            else if (!(EVC_WIDE_ABL & 2)) load_b(b[(T + EVC_WIDE_BDIST) % 3], (T + EVC_WIDE_BDIST < 9) ? c : cn, (T + EVC_WIDE_BDIST) % 9); \
             if (T == 0 && !(EVC_WIDE_ABL & 8)) coef_load(cn);                                           \
             if constexpr (LOADK >= 0 && LOADK < NU && !(EVC_WIDE_ABL & 8)) stage_load(LOADK < 0 ? 0 : LOADK, cn); \
             const char* An = (T == 8) ? Anxt : Acur;                /* image holding K-step T + 1 */    \
@@ -1602,7 +1745,14 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
         p.out[(size_t)m0 * p.ld_out + tid] = sacc;
         return;
     }
-    conv_epilogue<TM, TN, 2>(p, acc, m0, n0, split, wm, wn, l31, half, tail);
+    EVC_STAMP(2)
+    __syncthreads();                 // every wave has finished with the activation images: they become the epilogue's patches
+    wide_epilogue(p, acc, As, (EVC_WIDE_ABL & 128) ? 0 : m0, n0, split, wave, lane, tail);   // (diagnostic 128: every tile stores to tile 0's lines)
+#ifdef EVC_WIDE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    EVC_STAMP(3)
+    if (threadIdx.x == 0) g_wide_stamps[(blockIdx.x & 8191) * 8 + 4] = __builtin_amdgcn_s_getreg(6 | (8 << 6) | (3 << 11)) ;   // HW_ID: CU id bits
+#endif
 }
 
 // out = act((sum_z ws[z] + bias + res) * scale): deterministic split-K combine.
@@ -1932,8 +2082,10 @@ static long long wide_lds_bytes(int W, bool x2) { return (x2 ? 6LL : 4LL) * (256
 
 // conv_wide_kernel: f16x3, 3x3, 192-channel output tiles, 256-pixel tiles made of whole rows of one image
 static bool wide_ok(const evc_conv_args* a) {
-    return g_wide256 && a->arith == EVC_ARITH_F16X3 && a->KH == 3 && a->KW == 3 && a->Co % 192 == 0 &&
-           (a->W == 16 || a->W == 32 || a->W == 64 || a->W == 128) && ((long long)a->H * a->W) % 256 == 0;
+    const bool mode_ok = a->coef_a ? a->act_in == EVC_ACT_SILU : a->act_in == EVC_ACT_NONE;     // MODE_AFFINE_SILU / MODE_PLAIN
+    return g_wide256 && mode_ok && a->arith == EVC_ARITH_F16X3 && a->KH == 3 && a->KW == 3 && a->Co % 192 == 0 &&
+           (a->W == 16 || a->W == 32 || a->W == 64 || a->W == 128) && ((long long)a->H * a->W) % 256 == 0 &&
+           a->ld_out % 4 == 0 && (!a->res || a->ld_res % 4 == 0);      // the epilogue moves 16-byte pieces
 }
 
 static TileCfg conv_tile_cfg(const evc_conv_args* a) {
@@ -2128,20 +2280,29 @@ static int launch_split_rr(int mode, dim3 grid, size_t lds, hipStream_t st, cons
     return rc;
 }
 
-template <int MODE, int NU>
+template <int MODE, int NU, bool X2>
 static int launch_wide_one(dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
     static unsigned long long attr_done = 0;
-    const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_wide_kernel<MODE, NU>), &attr_done, lds);
+    const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_wide_kernel<MODE, NU, X2>), &attr_done, lds);
     if (rc != EVC_OK) return rc;
-    hipLaunchKernelGGL((conv_wide_kernel<MODE, NU>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((conv_wide_kernel<MODE, NU, X2>), grid, dim3(256), lds, st, k);
     return EVC_OK;
 }
-static int launch_wide(int mode, int nu, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
-    int rc = EVC_OK;
-#define EVC_CALL(M) rc = nu == 4 ? launch_wide_one<M, 4>(grid, lds, st, k) : launch_wide_one<M, 3>(grid, lds, st, k)
-    EVC_MODE_SWITCH(mode, EVC_CALL)
-#undef EVC_CALL
-    return rc;
+// the wide kernel is instantiated for the two load transforms the score network's 3x3 convolutions use: GroupNorm + SiLU on
+// load (MODE_AFFINE_SILU) and plain (inputs activated by the FIR pass); wide_ok() sends every other mode to the row-reuse kernel
+template <int MODE>
+static int launch_wide_mode(int nu, bool x2, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+    if (nu == 4) return x2 ? launch_wide_one<MODE, 4, true>(grid, lds, st, k) : launch_wide_one<MODE, 4, false>(grid, lds, st, k);
+    return x2 ? launch_wide_one<MODE, 3, true>(grid, lds, st, k) : launch_wide_one<MODE, 3, false>(grid, lds, st, k);
+}
+static int launch_wide(int mode, int nu, bool x2, dim3 grid, size_t lds, hipStream_t st, const ConvK& k) {
+#ifdef EVC_DEV_FAST
+    return launch_wide_mode<MODE_AFFINE_SILU>(nu, x2, grid, lds, st, k);
+#else
+    if (mode == MODE_AFFINE_SILU) return launch_wide_mode<MODE_AFFINE_SILU>(nu, x2, grid, lds, st, k);
+    if (mode == MODE_PLAIN) return launch_wide_mode<MODE_PLAIN>(nu, x2, grid, lds, st, k);
+    return EVC_EUNSUPPORTED;
+#endif
 }
 
 #define EVC_TN_SWITCH(tn, CALL) ((tn) == 3 ? CALL(3) : (tn) == 2 ? CALL(2) : CALL(1))
@@ -2227,7 +2388,7 @@ static int conv2d_impl(const evc_conv_args* a, float* ws, void* stream, hipEvent
     hipStream_t st = (hipStream_t)stream;
     if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return EVC_ELAUNCH;
     if (cfg.wide) {
-        rc = launch_wide(mode, a->W == 128 ? 4 : 3, grid, (size_t)wide_lds_bytes(a->W, a->x2_w_packed != nullptr), st, k);
+        rc = launch_wide(mode, a->W == 128 ? 4 : 3, a->x2_w_packed != nullptr, grid, (size_t)wide_lds_bytes(a->W, a->x2_w_packed != nullptr), st, k);
     } else if (is_split_arith(a->arith)) {
         const int np = arith_planes(a->arith);
         if (cfg.reuse) {
