@@ -131,7 +131,6 @@ def roofline_leg(net, clips, device):
     live_clock = probe.ghz()
     net.overlap_skip, net.use_graphs = overlap, graphs
     per, kern = {}, {}
-    mode_of = lambda c: (2 if c["act_in"] == L.ACT_SILU else 1) if c["coef"] else {L.ACT_SILU: 3, L.ACT_RELU: 4}.get(c["act_in"], 0)
     for r in prof:
         # e0..ec brackets the convolution kernel alone (recorded inside the C call, before the split-K combine kernel):
         # the duration rocprofv3 --kernel-trace reports for that kernel; e0..e1 includes the combine launch
@@ -140,17 +139,10 @@ def roofline_leg(net, clips, device):
         v["n"] += 1
         v["ms"] += ms_all
         v["flops"] += r["flops"]
-        # the kernel template instance this launch runs (csrc/conv_igemm.hip dispatch: row-reuse kernel for 3x3 filters on
-        # whole-row tiles, simple-schedule kernel otherwise) -- the name rocprofv3 --kernel-trace --stats reports
+        # the kernel template instance this launch runs, as the library's dispatch names it (evc_conv_kernel_name): the name
+        # rocprofv3 --kernel-trace --stats reports
         c = r["call"]
-        np_ = {1: 3, 2: 2}.get(r["arith"])
-        if np_ is None:
-            name = f"conv_igemm_kernel<2, {r['variant']}, {mode_of(c)}>"
-        elif c["K"] == 3 and 128 % c["W"] == 0:
-            name = f"conv_split_rr_kernel<{np_}, 2, {r['variant']}, {mode_of(c)}>"
-        else:
-            name = (f"conv_splitn_kernel<2, *, {r['variant']}, {mode_of(c)}>" if np_ == 2 else
-                    f"conv_split_kernel<*, {r['variant']}, {mode_of(c)}>")
+        name = r["kernel"]
         kv = kern.setdefault((name, r["arith"]), dict(n=0, ms=0.0, ms_all=0.0, flops=0.0, bytes=0.0))
         kv["n"] += 1; kv["ms"] += ms_k; kv["ms_all"] += ms_all; kv["flops"] += r["flops"]
         # algorithmic HBM bytes of the launch: every operand read once, the output written once (fp32 activations, the

@@ -28,6 +28,7 @@
 // nn.Linear (ncsnpp_more.py:89-95, layerspp.py:507) and the ELIC conv stacks (Network.py:106-166).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include "../../include/evc_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -2181,6 +2182,25 @@ extern "C" int evc_conv_fused_1x1_supported(const evc_conv_args* a) {
     if (a->arith != EVC_ARITH_F16X3 || a->KH != 3 || a->KW != 3) return 0;
     const TileCfg c = conv_tile_cfg(a);
     return (c.reuse == 1 || c.wide) ? 1 : 0;
+}
+
+// The kernel template instance evc_conv2d_nhwc_f32 launches for these arguments, as rocprofv3 --kernel-trace prints it
+// (without the namespace), e.g. "conv_wide_kernel<2, 4, false>".  Returns the length, or EVC_EINVAL.
+extern "C" int evc_conv_kernel_name(const evc_conv_args* a, char* buf, int n) {
+    if (!buf || n <= 0 || conv_validate(a) != EVC_OK) return EVC_EINVAL;
+    int mode;
+    if (a->coef_a) mode = a->act_in == EVC_ACT_SILU ? MODE_AFFINE_SILU : MODE_AFFINE;
+    else mode = a->act_in == EVC_ACT_SILU ? MODE_SILU : a->act_in == EVC_ACT_RELU ? MODE_RELU : MODE_PLAIN;
+    const TileCfg c = conv_tile_cfg(a);
+    int len;
+    if (c.wide) len = snprintf(buf, n, "conv_wide_kernel<%d, %d, %s>", mode, a->W == 128 ? 4 : 3, a->x2_w_packed ? "true" : "false");
+    else if (is_split_arith(a->arith)) {
+        const int np = arith_planes(a->arith);
+        if (c.reuse) len = snprintf(buf, n, "conv_split_rr_kernel<%d, %d, %d, %d>", np, c.bm == 256 ? 4 : 2, c.tn, mode);
+        else if (np == 3) len = snprintf(buf, n, "conv_split_kernel<%d, %d, %d>", c.tm, c.tn, mode);
+        else len = snprintf(buf, n, "conv_splitn_kernel<2, %d, %d, %d>", c.tm, c.tn, mode);
+    } else len = snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d>", c.tm, c.tn, mode);
+    return len;
 }
 
 extern "C" int evc_conv_choose_splits(const evc_conv_args* a) {

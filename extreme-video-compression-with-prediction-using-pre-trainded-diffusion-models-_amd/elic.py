@@ -27,7 +27,8 @@ GROUPS = [0, 16, 16, 32, 64, 192]   # Network.py:87
 ONE = np.ones((1, 1), dtype=np.float32)
 # Bumped whenever a change to the convolution kernels can alter the last bit of the entropy-parameter networks' outputs
 # (summation order, tile shapes ...): streams carry it (container.py) and receivers refuse a mismatch.
-ELIC_CODEC_REV = 3
+ELIC_CODEC_REV = 4
+ENTROPY_NETS = ("h_s", "cc_transforms", "context_prediction", "ParamAggregation")
 
 
 def _pad16(c):
@@ -40,6 +41,13 @@ class ElicModel:
         self.device = torch.device(device)
         self.N, self.M = N, M
         self.arith = L.default_arith()          # operand ranges are unknown here: never the fp16 split
+        # The entropy-parameter networks (h_s, cc_transforms, context_prediction, ParamAggregation: everything between the decoded
+        # integers and the means / scales the range coder is driven with) ALWAYS run under EVC_ARITH_F32: every output is one
+        # fixed-order chain of fmaf (v_mfma_f32_32x32x2_f32), which a CPU reproduces bit for bit (oracle/exact_conv.c).  A stream
+        # therefore decodes to the same symbols on any implementation of that arithmetic -- not only on this kernel build --
+        # which is what "bit-exact integer symbols" needs across implementations (tests/test_gpu_elic.py).  g_a / h_a / g_s are
+        # not part of that contract and keep the faster split arithmetic.
+        self.entropy_arith = L.ARITH_F32
         sd = state_dict
         self.w = {}
         for k in sd:
@@ -50,8 +58,9 @@ class ElicModel:
                                           "ParamAggregation"):
                 continue
             w = sd[k].detach().float()
+            arith = self.entropy_arith if name.split(".")[0] in ENTROPY_NETS else self.arith
             if self._is_deconv(name):                         # compressai deconv(): polyphase 3x3 form
-                self.w[name] = L.Deconv5x5s2(w, sd[name + ".bias"], self.arith, self.device)
+                self.w[name] = L.Deconv5x5s2(w, sd[name + ".bias"], arith, self.device)
                 continue
             if self._is_conv_s2(name):                        # compressai conv(): space-to-depth + 3x3
                 self.w[name] = L.Conv5x5s2(w, sd[name + ".bias"], self.arith, self.device)
@@ -69,7 +78,7 @@ class ElicModel:
                 wp = torch.zeros(co, cip, kh, kw)
                 wp[:, :ci] = w
                 w = wp
-            self.w[name] = dict(w=L.conv_pack_weights(w.to(self.device), self.arith), b=sd[name + ".bias"].detach().float().to(self.device),
+            self.w[name] = dict(w=L.conv_pack_weights(w.to(self.device), arith), b=sd[name + ".bias"].detach().float().to(self.device),
                                 co=co, k=kh)
         self.gc = Tables.from_state_dict(sd, "gaussian_conditional")
         self.scale_table = sd["gaussian_conditional.scale_table"].detach().float().to(self.device).contiguous()
@@ -77,8 +86,8 @@ class ElicModel:
                                          sd["entropy_bottleneck.quantiles"][:, 0, 1].detach().float().cpu().numpy())
 
     def codec_tag(self):
-        """(convolution arithmetic, kernel revision) the entropy parameters of this model are computed with."""
-        return (self.arith, ELIC_CODEC_REV)
+        """(convolution arithmetic, revision) the entropy parameters of this model are computed with."""
+        return (self.entropy_arith, ELIC_CODEC_REV)
 
     @staticmethod
     def _is_deconv(name):

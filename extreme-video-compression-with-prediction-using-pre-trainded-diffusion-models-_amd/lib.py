@@ -118,6 +118,7 @@ HIP_SYMBOLS = {
     "evc_spade_act_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                        c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "evc_conv_choose_splits": (c_int, [POINTER(ConvArgs)]),
+    "evc_conv_kernel_name": (c_int, [POINTER(ConvArgs), c_char_p, c_int]),
     "evc_conv_fused_1x1_supported": (c_int, [POINTER(ConvArgs)]),
     "evc_conv_stats_splits": (c_int, [POINTER(ConvArgs)]),
     "evc_conv_workspace_bytes": (c_longlong, [POINTER(ConvArgs)]),
@@ -495,7 +496,7 @@ def conv_pack_weights(w, arith=None):
 
 
 def conv_set_option(name, value):
-    """Dispatch switches of the convolution ("wide_tiles", "row_reuse", "tail_split"): include/evc_hip.h."""
+    """Dispatch switches of the convolution ("wide_tiles", "row_reuse", "tail_split", "wide256"): include/evc_hip.h."""
     _check(hip_lib(require_device=False).evc_conv_set_option(name.encode(), int(value)), "evc_conv_set_option")
 
 
@@ -605,7 +606,10 @@ def conv2d_nhwc(src0, w_packed, Co, KH, KW, bias=None, src1=None, coef=None, act
         _check(L.evc_conv2d_nhwc_profiled_f32(ctypes.byref(a), ptr(ws), stream_ptr(), c_void_p(e0.cuda_event),
                                               c_void_p(ec.cuda_event)), "evc_conv2d_nhwc_profiled_f32")
         e1.record(st)
+        kbuf = ctypes.create_string_buffer(96)
+        L.evc_conv_kernel_name(ctypes.byref(a), kbuf, 96)
         CONV_PROFILE.append(dict(variant=conv_variant(Co), split=nbytes > 0, e0=e0, ec=ec, e1=e1, arith=a.arith,
+                                 kernel=kbuf.value.decode(),
                                  flops=2.0 * B * H * W * Co * (KH * KW * (C0 + C1) + x2_ci),
                                  shape=(B, H, W, C0 + C1, Co, KH),
                                  call=dict(B=B, H=H, W=W, C0=C0, C1=C1, Co=Co, K=KH, coef=coef is not None, act_in=act_in,

@@ -199,9 +199,14 @@ long long evc_conv_packed_bytes(int Co, int Ci, int KH, int KW, int arith);
 int evc_conv_pack_weights(const float* w, void* packed, int Co, int Ci, int KH, int KW, int arith, void* stream);
 /* Process-wide tuning switches of the convolution dispatch (A/B measurements, tests of non-default kernels; results are
  * the same up to fp32 summation order): "wide_tiles" (default 1: 256-pixel row tiles on large unsplit grids), "row_reuse"
- * (default 1: the row-reuse kernel for 3x3 filters), "tail_split" (default 1: K-split tail of 1.x / 2.x-round grids).
+ * (default 1: the row-reuse kernel for 3x3 filters), "tail_split" (default 1: K-split tail of 1.x / 2.x-round grids), "wide256"
+ * (default 1: conv_wide_kernel, the 256 x 192 one-workgroup-per-CU f16x3 kernel, on grids of at least one full round).
  * Returns EVC_EINVAL for an unknown name. */
 int evc_conv_set_option(const char* name, int value);
+/* Name of the kernel template instance evc_conv2d_nhwc_f32 launches for these arguments, as rocprofv3 --kernel-trace --stats
+ * prints it (e.g. "conv_wide_kernel<2, 4, false>"): lets a profile be matched to launches without mirroring the dispatch.
+ * Returns the string length (truncated to n - 1) or EVC_EINVAL. */
+int evc_conv_kernel_name(const evc_conv_args* a, char* buf, int n);
 int evc_conv_choose_splits(const evc_conv_args* a);
 int evc_conv_fused_1x1_supported(const evc_conv_args* a);   /* 1: these arguments may carry the fused 1x1 operand */
 /* The number of pixel runs per image (H*W/64 or H*W/32) for which the fused moments will be written, when they are

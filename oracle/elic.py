@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from . import entropy as E
+from . import exact as X
 from . import rans as R
 
 GROUPS = [0, 16, 16, 32, 64, 192]   # Network.py:87
@@ -97,30 +98,44 @@ def h_a(p, y):
     return _conv(p, "h_a.4", x, 2, 2)
 
 
-def h_s(p, z):
-    """Network.py:132-138."""
+def h_s(p, z, exact=False):
+    """Network.py:132-138.  ``exact``: the product's fp32 arithmetic bit for bit (oracle/exact.py) instead of torch's."""
+    if exact:
+        x = X.deconv5x5s2(z, p["h_s.0.weight"], p["h_s.0.bias"], relu_out=True)
+        x = X.deconv5x5s2(x, p["h_s.2.weight"], p["h_s.2.bias"], relu_out=True)
+        return X.conv2d(x, p["h_s.4.weight"], p["h_s.4.bias"])
     x = F.relu(_deconv(p, "h_s.0", z))
     x = F.relu(_deconv(p, "h_s.2", x))
     return _conv(p, "h_s.4", x, pad=1)
 
 
-def _cc(p, i, x):
+def _cc(p, i, x, exact=False):
     """cc_transforms[i], Network.py:140-149 (5x5 stride-1 convs, padding 2)."""
     n = f"cc_transforms.{i}"
+    if exact:
+        x = X.conv2d(x, p[n + ".0.weight"], p[n + ".0.bias"], relu_out=True)
+        x = X.conv2d(x, p[n + ".2.weight"], p[n + ".2.bias"], relu_out=True)
+        return X.conv2d(x, p[n + ".4.weight"], p[n + ".4.bias"])
     x = F.relu(_conv(p, n + ".0", x, pad=2))
     x = F.relu(_conv(p, n + ".2", x, pad=2))
     return _conv(p, n + ".4", x, pad=2)
 
 
-def _ctx(p, i, x):
+def _ctx(p, i, x, exact=False):
     """CheckboardMaskedConv2d.forward, layers.py:84-88: weight * mask, 5x5, padding 2."""
     n = f"context_prediction.{i}"
+    if exact:
+        return X.conv2d(x, p[n + ".weight"] * p[n + ".mask"], p[n + ".bias"])
     return F.conv2d(x, p[n + ".weight"] * p[n + ".mask"], p[n + ".bias"], padding=2)
 
 
-def _pa(p, i, x):
+def _pa(p, i, x, exact=False):
     """ParamAggregation[i], Network.py:157-166."""
     n = f"ParamAggregation.{i}"
+    if exact:
+        x = X.conv2d(x, p[n + ".0.weight"], p[n + ".0.bias"], relu_out=True)
+        x = X.conv2d(x, p[n + ".2.weight"], p[n + ".2.bias"], relu_out=True)
+        return X.conv2d(x, p[n + ".4.weight"], p[n + ".4.bias"])
     x = F.relu(_conv(p, n + ".0", x))
     x = F.relu(_conv(p, n + ".2", x))
     return _conv(p, n + ".4", x)
@@ -157,18 +172,20 @@ def _tables(p, prefix):
             p[prefix + "._offset"].numpy().astype(np.int32))
 
 
-def _support(p, i, y_hat_slices, latent_means, latent_scales):
+def _support(p, i, y_hat_slices, latent_means, latent_scales, exact=False):
     if i == 0:
         return torch.cat([latent_means, latent_scales], dim=1)
     sup = y_hat_slices[0] if i == 1 else torch.cat([y_hat_slices[0], y_hat_slices[i - 1]], dim=1)
-    cc = _cc(p, i - 1, sup)
+    cc = _cc(p, i - 1, sup, exact)
     cc_mean, cc_scale = cc.chunk(2, 1)
     return torch.cat([cc_mean, cc_scale, latent_means, latent_scales], dim=1)
 
 
 @torch.no_grad()
-def compress(p, x, coder=R):
-    """TestModel.compress, Network.py:336-441 -> {"strings": [y_strings, z_strings], "shape"}; also returns y_hat."""
+def compress(p, x, coder=R, exact=False):
+    """TestModel.compress, Network.py:336-441 -> {"strings": [y_strings, z_strings], "shape"}; also returns y_hat.
+    ``exact``: the entropy-parameter networks (h_s, cc_transforms, context_prediction, ParamAggregation) in the product's
+    fp32 arithmetic bit for bit, so that the stream decodes on the HIP codec and vice versa (oracle/exact.py)."""
     y = g_a(p, x)
     B, C, H, W = y.shape
     z = h_a(p, y)
@@ -183,21 +200,21 @@ def compress(p, x, coder=R):
         z_strings.append(s)
         dec = np.asarray(coder.decode_with_indexes(s, z_idx.tolist(), cdf, cdf_len, off), dtype=np.float32)
         z_hat[b] = torch.from_numpy(dec.reshape(z.shape[1:])) + med[0]
-    latent_means, latent_scales = h_s(p, z_hat).chunk(2, 1)
+    latent_means, latent_scales = h_s(p, z_hat, exact).chunk(2, 1)
     gcdf, gcdf_len, goff = _tables(p, "gaussian_conditional")
     table = p["gaussian_conditional.scale_table"].numpy()
     y_slices = torch.split(y, GROUPS[1:], 1)
     y_strings, y_hat_slices = [], []
     for i, y_slice in enumerate(y_slices):
         g = GROUPS[i + 1]
-        support = _support(p, i, y_hat_slices, latent_means, latent_scales)
+        support = _support(p, i, y_hat_slices, latent_means, latent_scales, exact)
         strings_i = []
         y_hat_i = torch.zeros_like(y_slice)
         ctx = torch.zeros(B, 2 * g, H, W)
         for parity in (0, 1):
             if parity == 1:
-                ctx = _ctx(p, i, y_hat_i)        # anchors decoded, non-anchor sites still zero
-            means, scales = _pa(p, i, torch.cat([ctx, support], dim=1)).chunk(2, 1)
+                ctx = _ctx(p, i, y_hat_i, exact)        # anchors decoded, non-anchor sites still zero
+            means, scales = _pa(p, i, torch.cat([ctx, support], dim=1), exact).chunk(2, 1)
             m_enc, s_enc, y_enc = _pack(means, parity), _pack(scales, parity), _pack(y_slice, parity)
             idx = E.build_indexes(s_enc.numpy(), table)
             q = torch.zeros_like(m_enc)
@@ -217,8 +234,8 @@ def compress(p, x, coder=R):
 
 
 @torch.no_grad()
-def decompress(p, strings, shape, coder=R, return_latents=False):
-    """TestModel.decompress, Network.py:444-532."""
+def decompress(p, strings, shape, coder=R, return_latents=False, exact=False):
+    """TestModel.decompress, Network.py:444-532.  ``exact``: see ``compress``."""
     y_strings, z_strings = strings
     B = len(z_strings)
     cdf, cdf_len, off = _tables(p, "entropy_bottleneck")
@@ -229,20 +246,20 @@ def decompress(p, strings, shape, coder=R, return_latents=False):
     for b in range(B):
         dec = np.asarray(coder.decode_with_indexes(z_strings[b], z_idx.tolist(), cdf, cdf_len, off), dtype=np.float32)
         z_hat[b] = torch.from_numpy(dec.reshape(zc, shape[0], shape[1])) + med
-    latent_means, latent_scales = h_s(p, z_hat).chunk(2, 1)
+    latent_means, latent_scales = h_s(p, z_hat, exact).chunk(2, 1)
     H, W = z_hat.shape[2] * 4, z_hat.shape[3] * 4
     gcdf, gcdf_len, goff = _tables(p, "gaussian_conditional")
     table = p["gaussian_conditional.scale_table"].numpy()
     y_hat_slices, all_symbols = [], []
     for i in range(len(GROUPS) - 1):
         g = GROUPS[i + 1]
-        support = _support(p, i, y_hat_slices, latent_means, latent_scales)
+        support = _support(p, i, y_hat_slices, latent_means, latent_scales, exact)
         y_hat_i = torch.zeros(B, g, H, W)
         ctx = torch.zeros(B, 2 * g, H, W)
         for parity in (0, 1):
             if parity == 1:
-                ctx = _ctx(p, i, y_hat_i)
-            means, scales = _pa(p, i, torch.cat([ctx, support], dim=1)).chunk(2, 1)
+                ctx = _ctx(p, i, y_hat_i, exact)
+            means, scales = _pa(p, i, torch.cat([ctx, support], dim=1), exact).chunk(2, 1)
             m_enc, s_enc = _pack(means, parity), _pack(scales, parity)
             idx = E.build_indexes(s_enc.numpy(), table)
             q = torch.zeros_like(m_enc)

@@ -55,3 +55,33 @@ def test_synthetic_diffusion_weights_equal_oracle_recipe():
     assert list(sd) == list(ref)
     for k in sd:
         assert torch.equal(sd[k], ref[k]), k
+
+
+def test_exact_backend_restates_the_convolutions_and_round_trips():
+    """oracle/exact.py (the bit-exact restatement of the product's fp32 convolution arithmetic, C helper built by
+    oracle/Makefile): its convolutions equal torch's within fp32 round-off -- 3x3 / 5x5 / 1x1 "same" convolutions, the masked
+    context convolution, and the polyphase form of compressai's deconv (ConvTranspose2d k 5, stride 2, padding 2,
+    output_padding 1) -- and the oracle codec run in exact mode round-trips its own streams symbol for symbol."""
+    import torch.nn.functional as F
+    from oracle import exact as X
+    g = torch.Generator().manual_seed(7)
+    for (ci, co, k) in ((64, 96, 3), (48, 32, 5), (224, 128, 1), (20, 24, 3)):       # 20: channel padding to 32
+        x = torch.randn(2, ci, 8, 8, generator=g)
+        w = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+        b = torch.randn(co, generator=g)
+        ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=k // 2))
+        out = X.conv2d(x, w, b, relu_out=True)
+        assert float((out.double() - ref).abs().max()) < 1e-5 * float(ref.abs().max() + 1)
+        assert torch.equal(out, X.conv2d(x, w, b, relu_out=True))                      # deterministic
+    x = torch.randn(2, 192, 2, 2, generator=g)
+    wt = torch.randn(192, 100, 5, 5, generator=g) / (192 * 25) ** 0.5
+    b = torch.randn(100, generator=g)
+    ref = F.conv_transpose2d(x.double(), wt.double(), b.double(), stride=2, padding=2, output_padding=1)
+    out = X.deconv5x5s2(x, wt, b)
+    assert out.shape == (2, 100, 4, 4) and float((out.double() - ref).abs().max()) < 1e-5 * float(ref.abs().max() + 1)
+    # the codec in exact mode: encode -> decode returns the encoder's latents bit for bit
+    p = synthetic.elic_state_dict(5)
+    img = torch.rand(1, 3, 64, 64, generator=g)
+    enc = OEL.compress(p, img, coder=NativeCoder, exact=True)
+    dec = OEL.decompress(p, enc["strings"], enc["shape"], coder=NativeCoder, return_latents=True, exact=True)
+    assert torch.equal(dec["y_hat"], enc["y_hat"])
