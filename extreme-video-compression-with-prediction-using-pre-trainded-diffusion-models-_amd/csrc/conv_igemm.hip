@@ -138,62 +138,89 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[TM][TN], const float4 (
 // Epilogue shared by the convolution kernels.  C/D map of the 32x32 MFMA: col = lane & 31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Fuses bias + residual + scale + activation and, for full tiles, the
 // per-channel GroupNorm moments of the output; split-K launches write raw partial sums to their slab instead.
+// Full tiles: the wave-uniform cases (partial sums / residual / moments / output activation) are template parameters -- with
+// run-time branches inside the unrolled tiles the epilogue is a long chain of tiny basic blocks, each with its own waits
+// (measured on the wide kernel: 33 000 -> 13 000 cycles per 256 x 192 tile).  Same expressions, same order: bitwise the
+// results of the generic form.
+template <int TM, int TN, int WM, bool PARTIAL, bool RES, bool STATS, bool ACT>
+__device__ __forceinline__ void conv_epilogue_full(const ConvK& p, f32x16 (&acc)[TM][TN], int m0, int n0, int split,
+                                                   int wm, int wn, int l31, int half, bool tail) {
+    constexpr int BM = 32 * TM * WM;
+    const int ws_m0 = tail ? p.tail_first * BM : 0;          // slab row 0 = this pixel
+    const size_t ws_M = tail ? (size_t)p.tail_rows : (size_t)p.M;
+    const float ascale = p.w_hdr ? p.w_hdr[0] / in_scale(p) : 1.0f;
+    const float oscale = p.out_scale;
+    const int mw = m0 + wm * 32 * TM + 4 * half;
+    const int cw = n0 + wn * 32 * TN + l31;
+    const bool has_res = RES && (!ACT || p.res != nullptr), has_stats = STATS && (!ACT || p.stats != nullptr);   // ACT = the generic instance
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = cw + j * 32;
+        const float bias = (!PARTIAL && p.bias) ? p.bias[co] : 0.f;
+        float st_sum = 0.f, st_sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = mw + i * 32;
+            if (PARTIAL) {
+                float* o = p.ws + ((size_t)split * ws_M + (mb - ws_m0)) * p.Co + co;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * p.Co] = acc[i][j][r] * ascale;
+            } else {
+                float rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+                if (has_res) {
+                    const float* rp = p.res + (size_t)mb * p.ld_res + co;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = rp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ld_res];
+                }
+                float* o = p.out + (size_t)mb * p.ld_out + co;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = (acc[i][j][r] * ascale + bias + rv[r]) * oscale;
+                    if (ACT) v = act_fn(v, p.act_out);
+                    o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ld_out] = v;
+                    if (STATS) { st_sum += v; st_sq += v * v; }
+                }
+            }
+        }
+        // fused GroupNorm moments: this wave holds channel `co` of a whole 32*TM-pixel run (lanes l and l^32
+        // share the channel); one writer per (run, channel) => deterministic, no atomics.
+        if (has_stats) {
+            st_sum += __shfl_xor(st_sum, 32);
+            st_sq += __shfl_xor(st_sq, 32);
+            if (half == 0) {
+                float* sp = p.stats + ((size_t)(m0 / (32 * TM) + wm) * p.Co + co) * 2;
+                sp[0] = st_sum; sp[1] = st_sq;
+            }
+        }
+    }
+}
+
 template <int TM, int TN, int WM = 2>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][TN], int m0, int n0, int split,
                                               int wm, int wn, int l31, int half, bool tail = false) {
     constexpr int BM = 32 * TM * WM;       // WM = waves along the pixel dimension (2, or 4 in the 8-wave row-reuse kernel)
     constexpr int BN = 64 * TN;
     const bool partial = p.splits > 1 || tail;
+    if (m0 + BM <= p.M && n0 + BN <= p.Co) {
+#define EVC_EPI(PA, RE, ST, AC) conv_epilogue_full<TM, TN, WM, PA, RE, ST, AC>(p, acc, m0, n0, split, wm, wn, l31, half, tail)
+        if (partial) EVC_EPI(true, false, false, false);
+        else if (p.act_out != EVC_ACT_NONE) EVC_EPI(false, true, true, true);
+        else if (p.res && p.stats) EVC_EPI(false, true, true, false);
+        else if (p.stats) EVC_EPI(false, false, true, false);
+        else if (p.res) EVC_EPI(false, true, false, false);
+        else EVC_EPI(false, false, false, false);
+#undef EVC_EPI
+        return;
+    }
     const int ws_m0 = tail ? p.tail_first * BM : 0;          // slab row 0 = this pixel
     const size_t ws_M = tail ? (size_t)p.tail_rows : (size_t)p.M;
     // f16x3: the operands were scaled by powers of two to sit in fp16's range; undo it here (exact)
     const float ascale = p.w_hdr ? p.w_hdr[0] / in_scale(p) : 1.0f;
     const int mw = m0 + wm * 32 * TM + 4 * half;
     const int cw = n0 + wn * 32 * TN + l31;
-    if (m0 + BM <= p.M && n0 + BN <= p.Co) {
-        // full tile: straight-line code, residual loads batched ahead of the arithmetic
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int co = cw + j * 32;
-            const float bias = (!partial && p.bias) ? p.bias[co] : 0.f;
-            float st_sum = 0.f, st_sq = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int mb = mw + i * 32;
-                if (partial) {
-                    float* o = p.ws + ((size_t)split * ws_M + (mb - ws_m0)) * p.Co + co;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * p.Co] = acc[i][j][r] * ascale;
-                } else {
-                    float rv[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-                    if (p.res) {
-                        const float* rp = p.res + (size_t)mb * p.ld_res + co;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) rv[r] = rp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ld_res];
-                    }
-                    float* o = p.out + (size_t)mb * p.ld_out + co;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = act_fn((acc[i][j][r] * ascale + bias + rv[r]) * p.out_scale, p.act_out);
-                        o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ld_out] = v;
-                        st_sum += v; st_sq += v * v;
-                    }
-                }
-            }
-            // fused GroupNorm moments: this wave holds channel `co` of a whole 32*TM-pixel run (lanes l and l^32
-            // share the channel); one writer per (run, channel) => deterministic, no atomics.
-            if (!partial && p.stats) {
-                st_sum += __shfl_xor(st_sum, 32);
-                st_sq += __shfl_xor(st_sq, 32);
-                if (half == 0) {
-                    float* sp = p.stats + ((size_t)(m0 / (32 * TM) + wm) * p.Co + co) * 2;
-                    sp[0] = st_sum; sp[1] = st_sq;
-                }
-            }
-        }
-    } else {
+    {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int co = cw + j * 32;
@@ -1989,6 +2016,7 @@ struct TileCfg { int tm, tn, bm, bn; long long tiles; int splits; int reuse; int
 static int g_tail_split = EVC_CONV_TAIL;   // run-time option "tail_split"
 static int g_wide_tiles = EVC_SPLIT_WIDE_TILES;   // harness A/B switch for the 256-pixel row-reuse tiles
 static int g_no_reuse = 0;     // same: lets the harness A/B the row-reuse kernel inside one binary
+static int g_wide_mid = 1;     // run-time option "wide_mid": conv_wide_kernel with a uniform K split on grids below one round
 static int g_wide256 = 1;      // run-time option "wide256": the 256 x 192 one-workgroup-per-CU kernel (conv_wide_kernel) on grids of >= 1 round
 static int g_force_tm = 0;     // tools/conv_bench.hip (same translation unit) sets this to sweep tile heights; never set in the library
 
@@ -2156,6 +2184,30 @@ static TileCfg conv_tile_cfg(const evc_conv_args* a) {
             c.steps_per_split = nsteps;
             return c;
         }
+        // Grids below one round (64x64 / 32x32 layers at the benchmark batch): still one workgroup per CU, K split uniformly
+        // so that tiles x splits fills (at most) one round.  Per workgroup the kernel costs ~23 000 cycles (prologue + epilogue)
+        // + ~13 900 per chunk (profiles/r04_wide_stamps_v2.log); an unsplit grid on a little over half of the CUs still beats the
+        // 128-pixel tiles split three ways + their combine launch (64x64 192->192: ~95 vs 112 us).  g_wide_mid = 0 disables.
+        if (g_wide_mid && wgs >= 32) {
+            const int nchunk = (a->C0 + a->C1) / KC;
+            int best_s = 0;
+            double best_t = 1e300;
+            for (int sp = 1; sp <= 8 && wgs * sp <= 256 && nchunk / sp >= 4; ++sp) {
+                const int cps = (nchunk + sp - 1) / sp;
+                const double slab_mb = sp > 1 ? (double)sp * M * a->Co * 4.0 / 1e6 : 0.0;
+                const double t = 23000.0 + 13900.0 * cps + (sp > 1 ? 2.0 * 2000.0 * (5.0 + slab_mb / 4.0) : 0.0);   // cycles at ~2 GHz; combine: ~5 us + slabs at ~4 TB/s
+                if (t < best_t) { best_t = t; best_s = sp; }
+            }
+            // take it when a reasonable share of the machine is busy: below that the many-small-workgroups kernel wins
+            if (best_s > 0 && wgs * best_s >= 128) {
+                const int cps = (nchunk + best_s - 1) / best_s;
+                c.wide = 1; c.reuse = 0; c.tm = 4; c.tn = 3; c.bm = 256; c.bn = 192; c.tiles = wgs;
+                c.tail_first = 0; c.tail_tiles = 0; c.tail_splits = 1; c.tail_sps = 0;
+                c.splits = (nchunk + cps - 1) / cps;
+                c.steps_per_split = cps * 9;
+                return c;
+            }
+        }
     }
     // splits of the row-reuse kernel cover whole (chunk, kernel row) groups: 3 taps
     const int unit = c.reuse ? a->KW : 1;
@@ -2173,6 +2225,7 @@ extern "C" int evc_conv_set_option(const char* name, int value) {
     if (is("row_reuse")) { g_no_reuse = !value; return EVC_OK; }
     if (is("tail_split")) { g_tail_split = value; return EVC_OK; }
     if (is("wide256")) { g_wide256 = value; return EVC_OK; }
+    if (is("wide_mid")) { g_wide_mid = value; return EVC_OK; }
     return EVC_EINVAL;
 }
 
