@@ -1564,7 +1564,7 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
     // pixels are staged raw (scaled from x2's element bound) at the centre of the image, fragments read at the centre tap.
     // Software pipeline over THREE LDS images so that one barrier per chunk is enough and nothing waits behind it: during the
     // MFMAs of chunk c the fragments of chunk c + 1 are read (image published by the previous barrier), chunk c + 2 is
-    // transformed and written (its loads were issued a chunk earlier) and the loads of chunk c + 3 are issued. ----
+    // transformed and written (its loads were issued two chunks earlier) and the loads of chunk c + 4 are issued. ----
     if constexpr (X2) {
         const int nch2 = (p.x2_C0 + p.x2_C1) / KC;
         const int nsp = tail ? p.tail_splits : p.splits;
@@ -1578,7 +1578,7 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
         }
         const float xscale2 = F16_ACT_SCALE * s2;
         const unsigned slab2 = 2u * planeB;
-        float4 x2r[2][2];
+        float4 x2r[2][2][2];                  // [register set][unit][float4]: a chunk's loads are issued TWO steps before its store
         unsigned x2o0[2], x2o1[2];
         int x2l[2];
 #pragma unroll
@@ -1589,7 +1589,7 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
             x2o1[k] = ((unsigned)(m0 + pp) * (unsigned)p.x2_ld1 + 8u * kh) * 4u;
             x2l[k] = kh * HPL + ((r + 1) * SW + x + 1) * 16;
         }
-        auto load2 = [&](int c) {
+        auto load2 = [&](int c, float4 (&xr2)[2][2]) {
             const int cc = c * KC;
             const bool first = cc < p.x2_C0;
             const char* src = reinterpret_cast<const char*>(first ? p.x2_src0 : p.x2_src1);
@@ -1597,16 +1597,16 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const unsigned o = (first ? x2o0[k] : x2o1[k]) + cb;
-                x2r[k][0] = *reinterpret_cast<const float4*>(src + o);
-                x2r[k][1] = *reinterpret_cast<const float4*>(src + o + 16);
+                xr2[k][0] = *reinterpret_cast<const float4*>(src + o);
+                xr2[k][1] = *reinterpret_cast<const float4*>(src + o + 16);
             }
         };
-        auto store2 = [&](int buf) {
+        auto store2 = [&](int buf, float4 (&xr2)[2][2]) {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 vec pl[2];
-                SP::split(transform<MODE_PLAIN>(x2r[k][0], z, z, true), transform<MODE_PLAIN>(x2r[k][1], z, z, true), xscale2, pl);
+                SP::split(transform<MODE_PLAIN>(xr2[k][0], z, z, true), transform<MODE_PLAIN>(xr2[k][1], z, z, true), xscale2, pl);
                 char* A = As + buf * 2 * APL + x2l[k];
                 *reinterpret_cast<vec*>(A) = pl[0];
                 *reinterpret_cast<vec*>(A + APL) = pl[1];
@@ -1624,22 +1624,23 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
         const int n2 = c2e - c2b;
         if (n2 > 0) {
             const auto clampc = [&](int c) { return min(c, c2e - 1); };
-            load2(c2b);
+            load2(c2b, x2r[0]);
+            load2(clampc(c2b + 1), x2r[1]);
             load_b2(b2[0], c2b);
-            store2(0);
-            load2(clampc(c2b + 1));
-            store2(1);
-            load2(clampc(c2b + 2));
+            store2(0, x2r[0]);
+            store2(1, x2r[1]);
+            load2(clampc(c2b + 2), x2r[0]);
+            load2(clampc(c2b + 3), x2r[1]);
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < TM; ++i) read_a(i, As, tap_off(4));
             // three images: chunk k of this phase lives in image k % 3 (ring index kept without a division)
             int ring = 0;
-#define EVC_WIDE_X2_STEP(BCUR, BNXT)                                                                    \
+#define EVC_WIDE_X2_STEP(BCUR, BNXT, XR)                                                                    \
             {                                                                                           \
                 const int rn1 = ring == 2 ? 0 : ring + 1, rn2 = rn1 == 2 ? 0 : rn1 + 1;                 \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j) { EVC_PIN(BCUR[j][0]); EVC_PIN(BCUR[j][1]); } \
-                _Pragma("unroll") for (int k = 0; k < 2; ++k) { EVC_PIN4(x2r[k][0]); EVC_PIN4(x2r[k][1]); } \
+                _Pragma("unroll") for (int k = 0; k < 2; ++k) { EVC_PIN4(XR[k][0]); EVC_PIN4(XR[k][1]); } \
                 load_b2(BNXT, clampc(c + 1));                                                           \
                 const char* An = As + rn1 * 2 * APL;                                                    \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                        \
@@ -1647,7 +1648,7 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
                     EVC_WIDE_MFMA_I(i, BCUR)                                                            \
                     read_a(i, An, tap_off(4));                                                          \
                 }                                                                                       \
-                store2(rn2);                                 /* chunk c + 2 */                          \
+                store2(rn2, XR);                             /* chunk c + 2 */                          \
                 _Pragma("unroll") for (int m = 0; m < 36; ++m) {                                        \
                     if (m == 0) __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);                      \
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
@@ -1656,19 +1657,19 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
                 }                                                                                       \
                 __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                      \
-                load2(clampc(c + 3));                                                                   \
+                load2(clampc(c + 4), XR);                    /* stored two steps from now */            \
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                         \
                 __builtin_amdgcn_sched_barrier(0);                                                      \
                 ring = rn1;                                                                             \
             }
             int c = c2b;
             for (; c + 1 < c2e; c += 2) {
-                EVC_WIDE_X2_STEP(b2[0], b2[1])
+                EVC_WIDE_X2_STEP(b2[0], b2[1], x2r[0])
                 ++c;
-                EVC_WIDE_X2_STEP(b2[1], b2[0])
+                EVC_WIDE_X2_STEP(b2[1], b2[0], x2r[1])
                 --c;
             }
-            if (c < c2e) EVC_WIDE_X2_STEP(b2[0], b2[1])
+            if (c < c2e) EVC_WIDE_X2_STEP(b2[0], b2[1], x2r[0])
 #undef EVC_WIDE_X2_STEP
         }
         __syncthreads();
