@@ -155,7 +155,7 @@ def roofline_leg(net, clips, device):
     total_flops = sum(v["flops"] for v in per.values()) / reps
     # THE dominant kernel: the template instance with the largest share of the convolution time.  achieved = its algorithmic
     # FLOPs per launch / its average launch duration (the kernel alone); the committed rocprofv3 --kernel-trace --stats CSV of
-    # the same forward (profiles/r03_forward_b9_kernel_stats.csv, side stream off like this leg) holds the same average.
+    # the same forward (profiles/r04_forward_b9_kernel_stats.csv, side stream off like this leg) holds the same average.
     (dk_name, dk_arith), dk = max(kern.items(), key=lambda kv: kv[1]["ms"])
     aname, peak, basis = ARITH_INFO[dk_arith]
     us = dk["ms"] / dk["n"] * 1e3
@@ -171,12 +171,12 @@ def roofline_leg(net, clips, device):
            "achieved_over_f32_mfma_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 3)}
     try:
         import csv
-        meta = json.load(open(os.path.join(REPO, "profiles", "r03_forward_b9_kernel_stats.json")))
+        meta = json.load(open(os.path.join(REPO, "profiles", "r04_forward_b9_kernel_stats.json")))
         if meta.get("source_sha") == source_sha() and meta.get("batch") == clips:
-            for row in csv.DictReader(open(os.path.join(REPO, "profiles", "r03_forward_b9_kernel_stats.csv"))):
+            for row in csv.DictReader(open(os.path.join(REPO, "profiles", "r04_forward_b9_kernel_stats.csv"))):
                 if dk_name in row["Name"]:
                     rus = float(row["AverageNs"]) / 1e3
-                    out["rocprof"] = {"csv": "profiles/r03_forward_b9_kernel_stats.csv", "avg_us": round(rus, 2),
+                    out["rocprof"] = {"csv": "profiles/r04_forward_b9_kernel_stats.csv", "avg_us": round(rus, 2),
                                       "calls": int(row["Calls"]), "frac": round(gflop * 1e9 / (rus * 1e-6) / 1e12 / peak, 4)}
                     break
             if meta.get("held_clock_ghz"):
@@ -184,28 +184,28 @@ def roofline_leg(net, clips, device):
             if meta.get("mfma_busy_frac"):
                 out["mfma_busy_frac_pmc"] = meta["mfma_busy_frac"]
         else:
-            out["rocprof"] = (f"profiles/r03_forward_b9_kernel_stats.csv was taken on source {meta.get('source_sha')} at "
+            out["rocprof"] = (f"profiles/r04_forward_b9_kernel_stats.csv was taken on source {meta.get('source_sha')} at "
                               f"B={meta.get('batch')}, this is {source_sha()} at B={clips}: not quoted")
     except Exception:
         pass
     if live_clock:
-        # the chip does not hold its 2.4 GHz peak under these kernels: the package sits at its 1 400 W power cap (profiles/NOTES.md,
-        # r03_power_cap.log) and the shader clock settles where the cap puts it; `peak` is priced at 2.4 GHz regardless
+        # the chip does not hold its 2.4 GHz peak under these kernels (~2.05 GHz across a forward at ~1 000 W of the 1 400 W cap;
+        # back-to-back launches of the heavy kernels reach the cap, profiles/r03_power_cap.log); `peak` is priced at 2.4 GHz regardless
         out["held_clock_ghz"] = round(live_clock, 3)
         out["held_clock_note"] = ("s_memtime / s_memrealtime of an idle probe wave (evc_clock_probe) across these forwards; "
                                   "2.4 GHz is the clock `peak` assumes")
         out["frac_at_held_clock"] = round(achieved / (peak * live_clock / 2.4), 4)
     prov = "no rocprofv3 PMC profile committed for this kernel source"
     try:       # HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, only if taken on THIS source
-        pmc = json.load(open(os.path.join(REPO, "profiles", f"r03_conv_{aname}_pmc.json")))
+        pmc = json.load(open(os.path.join(REPO, "profiles", f"r04_conv_{aname}_pmc.json")))
         if pmc.get("source_sha") != source_sha():
-            prov = f"profiles/r03_conv_{aname}_pmc.json is stale (taken on source {pmc.get('source_sha')}): not reported"
+            prov = f"profiles/r04_conv_{aname}_pmc.json is stale (taken on source {pmc.get('source_sha')}): not reported"
         elif clips != pmc.get("batch") or pmc.get("kernel") != dk_name:
-            prov = f"profiles/r03_conv_{aname}_pmc.json covers {pmc.get('kernel')} at B={pmc.get('batch')}"
+            prov = f"profiles/r04_conv_{aname}_pmc.json covers {pmc.get('kernel')} at B={pmc.get('batch')}"
         else:
             out["traffic"] = pmc["hbm_bytes_per_launch"]
             out["traffic_over_algorithmic_bytes"] = round(pmc["hbm_bytes_per_launch"] / (dk["bytes"] / dk["n"]), 2)
-            prov = f"profiles/r03_conv_{aname}_pmc.json, source {pmc['source_sha']}, FETCH_SIZE x2 + WRITE_SIZE"
+            prov = f"profiles/r04_conv_{aname}_pmc.json, source {pmc['source_sha']}, FETCH_SIZE x2 + WRITE_SIZE"
     except Exception:
         pass
     out["traffic_provenance"] = prov
@@ -224,8 +224,8 @@ def roofline_leg(net, clips, device):
                    "runs with it on); `families` / conv_ms_per_forward include the split-K combine launches.  Inside a forward the "
                    "heavy convolution launches alternate with light kernels: the package averages ~1 000 W of its 1 400 W cap and "
                    "holds ~2.05 GHz (held_clock_ghz), so frac is bounded by CYCLES -- non-MFMA work per MFMA in the K loop "
-                   "(operand staging, weight delivery, fragment reads; DESIGN.md section 9) -- not by the power cap; only "
-                   "back-to-back launches of this kernel alone reach the cap (1.83 GHz, profiles/r03_power_cap.log)")
+                   "(weight-fragment loads ~26 %, operand staging arithmetic ~14 %, epilogue + prologue ~12 % of a tile: "
+                   "profiles/r04_wide_ablation_duty.log, r04_wide_stamps_v2.log; DESIGN.md section 9) -- not by the power cap")
     return out
 
 
