@@ -18,4 +18,10 @@ What is restated here, and what pins it:
   installed, so the reference ELIC modules cannot be imported here).
   PARITY UNPINNED: written from the reference source text and from the published
   compressai / ryg_rans algorithm; the reference holds no golden vector for this path.
+* ``exact.py`` + ``exact_conv.c`` (built by ``oracle/Makefile`` into ``oracle/_build/``) -- a
+  bit-exact C restatement of the PRODUCT's fp32 convolution arithmetic (one fixed-order chain
+  of fmaf per output element).  ``elic.py`` runs the entropy-parameter networks through it
+  when asked for ``exact=True``: the oracle then derives bit-identical means / scales, symbols
+  and bytes as the HIP codec (tests/test_gpu_elic.py, both directions, no teacher forcing).
+  This pins the two implementations to each other; it does not pin either to compressai.
 """
