@@ -277,6 +277,66 @@ def test_conv3x3_with_fused_1x1_operand(L, B, H, W, C, Co, C2a, C2b, splits):
         L.conv2d_nhwc(h, L.conv_pack_weights(w1, L.ARITH_BF16X6), Co, 3, 3, bias=b1, x2=(xa, xb, wp2, bound))
 
 
+@pytest.mark.parametrize("B,H,W,C0,C1,Co,mode,what", [
+    (4, 128, 128, 32, 16, 192, "gn", "256 tiles = exactly one round, two sources"),
+    (5, 128, 128, 192, 0, 192, "gn", "320 tiles: one round + a 4-way K-split tail (12 chunks)"),
+    (5, 128, 128, 48, 0, 192, "plain", "320 tiles, 3 chunks: tail too short to split -> a second round of whole tiles"),
+    (9, 64, 64, 96, 0, 384, "gn", "288 workgroups over two channel tiles: one round + a split tail"),
+    (9, 64, 64, 64, 0, 192, "plain", "144 tiles, 4 chunks: below one round, unsplit"),
+    (9, 32, 32, 128, 64, 384, "gn", "72 tiles, 12 chunks: below one round, uniform 3-way K split + combine"),
+    (64, 16, 16, 64, 0, 384, "gn", "W = 16: sixteen image rows per tile"),
+])
+def test_conv_wide_kernel_against_torch_and_the_row_reuse_kernel(L, B, H, W, C0, C1, Co, mode, what):
+    """conv_wide_kernel (round 4: 256 x 192 tile, one 4-wave workgroup per CU, weights from L2 straight into registers, nine taps
+    from one staged chunk image) on every grid class its dispatch takes -- whole rounds, round + K-split tail, sub-round grids
+    unsplit and uniformly split -- and every image width: against torch in fp64 (GroupNorm + SiLU on load or plain, bias,
+    residual, 1 / sqrt(2)), its fused moments against the output, and against the row-reuse kernel the same call ran on before
+    (dispatch option "wide256" = 0): two kernels, one result up to fp32 summation order."""
+    x0 = rnd(70, B, C0, H, W).cuda()
+    x1 = rnd(71, B, C1, H, W).cuda() if C1 else None
+    C = C0 + C1
+    a, s = (1 + 0.2 * rnd(72, B, C)).cuda(), (0.3 * rnd(73, B, C)).cuda()
+    w = (rnd(74, Co, C, 3, 3) / np.sqrt(9 * C)).cuda()
+    b, res = rnd(75, Co).cuda(), rnd(76, B, Co, H, W).cuda()
+    wp = L.conv_pack_weights(w, L.ARITH_F16X3)
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    kw = dict(bias=b, src1=None if x1 is None else nhwc(x1), res=nhwc(res), out_scale=0.70710678, want_stats=True)
+    if mode == "gn":
+        kw.update(coef=(a, s), act_in=L.ACT_SILU)
+        pre = silu_affine(xin, a, s)
+    else:
+        pre = xin
+    ref = (F.conv2d(pre.double(), w.double(), b.double(), padding=1) + res.double()) * 0.70710678
+
+    def run():
+        prof = []
+        L.CONV_PROFILE = prof
+        try:
+            r = L.conv2d_nhwc(nhwc(x0), wp, Co, 3, 3, **kw)
+        finally:
+            L.CONV_PROFILE = None
+        return r, prof[0]["kernel"]
+
+    def moments(t):
+        o = t.double().reshape(B, H * W, Co)
+        return torch.stack([o.sum(1), (o * o).sum(1)], -1).float()
+    (out, st), kernel = run()
+    assert kernel.startswith("conv_wide_kernel<"), (what, kernel)
+    err = float((nchw(out).double() - ref).abs().max() / ref.abs().max())
+    assert err < 3e-6, (what, err)
+    assert rel(st.double().sum(1).float(), moments(out)) < 1e-5, what
+    again, _ = L.conv2d_nhwc(nhwc(x0), wp, Co, 3, 3, **kw)
+    assert torch.equal(again, out), what                                   # deterministic
+    try:
+        L.conv_set_option("wide256", 0)
+        (old, st_old), kernel = run()
+    finally:
+        L.conv_set_option("wide256", 1)
+    assert not kernel.startswith("conv_wide_kernel<"), (what, kernel)
+    assert rel(out, old) < 2e-6, what
+    assert rel(st_old.double().sum(1).float(), moments(old)) < 1e-5, what
+
+
 def test_conv_bf16x6_is_not_less_accurate_than_f32_mfma(L):
     """The precision claim of EVC_ARITH_BF16X6 and EVC_ARITH_F16X3, on the real kernels: against an fp64 reference
     their error is no larger than that of the exact-product f32 MFMA path (all accumulate in fp32), for the dominant
