@@ -453,6 +453,55 @@ def gen_forward_spade():
     save("forward_spade", out_t0=o0, out_t990_3=o1, out_tm05=o2)
 
 
+def pseudo3d_dims():
+    return Dims(ngf=32, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16, 8], n_head_channels=32, image_size=16,
+                channels=3, num_frames=3, num_frames_cond=2)
+
+
+def gen_forward_pseudo3d():
+    """``model.arch: unetmorepseudo3d`` (ncsnpp_more.py:40-51,101-122 + models/better/layers3d.py), reduced size: every 3x3 /
+    1x1 convolution a per-frame Conv2d -> SiLU -> Conv1d over the frames, GroupNorm over (C / G, N, H, W), space-then-time
+    attention, and the 1x1 "converters" from 5 frames (3 + 2 conditioning) to 3.  Outputs at three labels + strided samples
+    of every module's output (forward hooks)."""
+    from models.better.ncsnpp_more import UNetMore_DDPM
+    from oracle import scorenet_pseudo3d as O3
+    d = pseudo3d_dims()
+    cfg = ref_config(d.ngf, d.n_head_channels, d.image_size, arch="unetmorepseudo3d", ch_mult=d.ch_mult,
+                     num_res_blocks=d.num_res_blocks, attn_resolutions=d.attn_resolutions)
+    cfg.data.num_frames, cfg.data.num_frames_cond, cfg.data.num_frames_future = d.num_frames, d.num_frames_cond, 0
+    net = UNetMore_DDPM(cfg).eval()
+    p = O3.seeded_params(d, 91)
+    own = dict(net.named_parameters())
+    assert set(own) == set(p), sorted(set(own) ^ set(p))[:8]
+    assert [k for k in own] == [k for k in p], "state_dict order"
+    for k, v in p.items():
+        assert tuple(own[k].shape) == tuple(v.shape), (k, tuple(own[k].shape), tuple(v.shape))
+    missing, unexpected = net.load_state_dict(p, strict=False)
+    assert not unexpected and all(m in ("betas", "alphas", "alphas_prev", "unet.sigmas") for m in missing), missing
+    B = 2
+    x, cond = rnd(92, B, 3 * d.num_frames, 16, 16), rnd(93, B, 3 * d.num_frames_cond, 16, 16)
+    taps = {}
+    hooks = [m.register_forward_hook(lambda mod, i, o, idx=idx: taps.__setitem__(idx, o.detach().clone()))
+             for idx, m in enumerate(net.unet.all_modules)]
+    with torch.no_grad():
+        o1 = net(x, torch.tensor([430, 7]), cond=cond)
+    for h in hooks:
+        h.remove()
+    with torch.no_grad():
+        o0 = net(x, torch.tensor([0, 0]), cond=cond)
+        o2 = net(x, torch.tensor([-0.5, -0.5]), cond=cond)
+    samples = {}
+    for idx, t in taps.items():
+        if idx < 2 or t.dim() != 4:
+            continue
+        flat = t.reshape(-1)
+        stride = max(1, flat.numel() // 512)
+        samples[f"tap{idx}"] = flat[::stride][:512].clone()
+        samples[f"tapstat{idx}"] = torch.stack([t.mean(), t.std()])
+        samples[f"tapshape{idx}"] = torch.tensor(t.shape)
+    save("forward_pseudo3d", out_t0=o0, out_t430_7=o1, out_tm05=o2, **samples)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -461,7 +510,8 @@ if __name__ == "__main__":
     gens = dict(schedule=gen_schedule, fir=gen_fir, blocks=gen_blocks, forward_reduced=gen_forward_reduced,
                 samplers=gen_samplers, sampler_options=gen_sampler_options, sampler_gamma=gen_sampler_gamma, model_options=gen_model_options, lpips_lin=gen_lpips_lin,
                 forward_full=gen_forward_full, forward_full_b9=gen_forward_full_b9,
-                traj_full=gen_traj_full, traj_fpndm_full=gen_traj_fpndm_full, traj_ddim_full=gen_traj_ddim_full, unet_ddpm=gen_unet_ddpm, forward_spade=gen_forward_spade)
+                traj_full=gen_traj_full, traj_fpndm_full=gen_traj_fpndm_full, traj_ddim_full=gen_traj_ddim_full, unet_ddpm=gen_unet_ddpm, forward_spade=gen_forward_spade,
+                forward_pseudo3d=gen_forward_pseudo3d)
     for name, fn in gens.items():
         if a.only and name != a.only:
             continue

@@ -244,3 +244,37 @@ def test_spade_scorenet_oracle_matches_reference_goldens():
         ref = g[key]
         assert float(np.abs(out.numpy() - ref).max() / np.abs(ref).max()) < 2e-5, key
     assert not np.array_equal(g["out_t0"], g["out_t990_3"])
+
+
+def pseudo3d_dims():
+    """The reduced ``unetmorepseudo3d`` configuration of tests/golden/make_goldens.py::gen_forward_pseudo3d."""
+    return Dims(ngf=32, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16, 8], n_head_channels=32, image_size=16,
+                channels=3, num_frames=3, num_frames_cond=2)
+
+
+def test_pseudo3d_scorenet_oracle_matches_reference_goldens():
+    """``model.arch: unetmorepseudo3d`` (ncsnpp_more.py is3d / pseudo3d branches + models/better/layers3d.py): the oracle's
+    forward at integer, mixed and fractional labels and the output of every module of ``all_modules`` (pseudo-3-D
+    convolutions, 3-D AdaGN res-blocks, space + time attention, frame converters) against the reference's own."""
+    from oracle import scorenet_pseudo3d as O3
+    g = golden("forward_pseudo3d")
+    d = pseudo3d_dims()
+    p = O3.seeded_params(d, 91)
+    x, cond = rnd(92, 2, 9, 16, 16), rnd(93, 2, 6, 16, 16)
+    for key, lab in (("out_t0", [0, 0]), ("out_tm05", [-0.5, -0.5])):
+        assert _rel(O3.forward(p, d, x, torch.tensor(lab), cond=cond).numpy(), g[key]) < 2e-5, key
+    taps = {}
+    out = O3.forward(p, d, x, torch.tensor([430, 7]), cond=cond, taps=taps)
+    assert _rel(out.numpy(), g["out_t430_7"]) < 2e-5
+    mods = O3.program(d)
+    kinds = {}
+    for idx, m in enumerate(mods):
+        if m["kind"] in ("linear", "norm"):
+            continue
+        t = taps[idx]
+        assert tuple(t.shape) == tuple(g[f"tapshape{idx}"]), (idx, m)
+        flat = t.reshape(-1)
+        stride = max(1, flat.numel() // 512)
+        assert _rel(flat[::stride][:512].numpy(), g[f"tap{idx}"]) < 2e-5, (idx, m)
+        kinds[m["kind"]] = kinds.get(m["kind"], 0) + 1
+    assert kinds == dict(conv3=2, res=10, attn=5, mix=5), kinds
