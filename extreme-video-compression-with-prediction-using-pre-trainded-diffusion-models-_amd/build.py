@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-HIP_SOURCES = ["conv_igemm.hip", "attention.hip", "norm.hip", "fir.hip", "elementwise.hip", "gdn.hip", "stride2.hip", "lpips.hip", "api.hip"]
+HIP_SOURCES = ["conv_igemm.hip", "attention.hip", "norm.hip", "fir.hip", "elementwise.hip", "gdn.hip", "stride2.hip", "lpips.hip", "frames.hip", "api.hip"]
 ARCH = "gfx950"
 
 

@@ -129,6 +129,9 @@ HIP_SYMBOLS = {
     "evc_attention_workspace_bytes": (c_longlong, [c_int, c_int, c_int, c_int]),
     "evc_attention_ws_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_float, c_void_p, c_void_p]),
+    "evc_frame_group_norm_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_float, c_void_p]),
+    "evc_frame_attention_f32": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_int] * 5 + [c_float, c_void_p]),
+    "evc_frame_mix_f32": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_longlong, c_void_p]),
     "evc_ddpm_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong] + [c_float] * 5 + [c_int, c_void_p]),
     "evc_ddim_step_f32": (c_int, [c_void_p, c_void_p, c_longlong] + [c_float] * 4 + [c_int, c_void_p]),
     "evc_axpy_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_void_p]),
@@ -661,6 +664,38 @@ def attention(qkv, C, heads, out=None, bounds=None):
     _check(L.evc_attention_ws_f32(c_void_p(base), c_void_p(base + 4 * C), c_void_p(base + 8 * C), ld, fptr(out), C, B,
                                   heads, N, D, float(int(D) ** (-0.5)), ptr(ws), stream_ptr()), "evc_attention_ws_f32")
     return out
+
+
+def frame_group_norm(x, N, gamma, beta, groups, eps):
+    """GroupNorm over (C / groups channels x N frames) of each pixel, affine.  x: (B*N, H, W, C), a sample's frames adjacent."""
+    BN, H, W, C = x.shape
+    assert BN % N == 0 and x.is_contiguous()
+    y = torch.empty_like(x)
+    _check(hip_lib().evc_frame_group_norm_f32(fptr(x), fptr(y), fptr(gamma), fptr(beta), BN // N, N, H * W, C, groups,
+                                              float(eps), stream_ptr()), "evc_frame_group_norm_f32")
+    return y
+
+
+def frame_attention(qkv, N, C, heads):
+    """Attention over the N frames of each pixel.  qkv: (B*N, H, W, 3C) with q | k | v along channels; returns (B*N, H, W, C)."""
+    BN, H, W, ld = qkv.shape
+    assert BN % N == 0 and ld == 3 * C and qkv.is_contiguous()
+    out = torch.empty((BN, H, W, C), device=qkv.device, dtype=torch.float32)
+    _check(hip_lib().evc_frame_attention_f32(fptr(qkv), ld, fptr(out), C, BN // N, N, H * W, C, heads,
+                                             float(int(C // heads) ** (-0.5)), stream_ptr()), "evc_frame_attention_f32")
+    return out
+
+
+def frame_mix(x, N, w, bias):
+    """1x1 convolution over the frame axis: x (B*N, H, W, C), w (M, N) -> (B*M, H, W, C)."""
+    BN, H, W, C = x.shape
+    M = w.shape[0]
+    assert BN % N == 0 and tuple(w.shape) == (M, N) and x.is_contiguous() and w.is_contiguous()
+    B = BN // N
+    y = torch.empty((B * M, H, W, C), device=x.device, dtype=torch.float32)
+    _check(hip_lib().evc_frame_mix_f32(fptr(x), fptr(y), fptr(w), fptr(bias), B, N, M, H * W * C, stream_ptr()),
+           "evc_frame_mix_f32")
+    return y
 
 
 class Deconv5x5s2:

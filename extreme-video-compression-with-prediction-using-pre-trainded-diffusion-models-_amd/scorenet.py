@@ -170,6 +170,7 @@ class ScoreNet(DdpmWrapper):
     options (ncsnpp_more.py:61,97-99,282-285,735-768)."""
 
     SPADE = False      # scorenet_spade.SpadeScoreNet: conditioning through SPADE act-norms (model.spade: true)
+    ARCH = "unetmore"  # scorenet_pseudo3d.Pseudo3dScoreNet: "unetmorepseudo3d"
 
     def __init__(self, config, state_dict, device="cuda", prefix="", preactivate=False, use_graphs=False):
         L.hip_lib()   # fail loudly before touching anything else
@@ -184,18 +185,19 @@ class ScoreNet(DdpmWrapper):
         self.d = dims_from_config(config)
         self.type = getattr(config.model, "type", "v1")
         m = config.model
-        if bool(getattr(m, "spade", False)) != self.SPADE or getattr(m, "output_all_frames", False) or m.arch != "unetmore":
-            raise NotImplementedError("only arch=unetmore without output_all_frames is built: the concat-conditioned network "
-                                      "of configs/mine.yml (ScoreNet) and its SPADE variant (SpadeScoreNet); 3-D / pseudo-3-D "
-                                      "archs are not (SURVEY.md section 2); output_all_frames fails in the reference itself "
-                                      "(ncsnpp_more.py:384-385 splits 15 channels into 6 + 15)")
+        if bool(getattr(m, "spade", False)) != self.SPADE or getattr(m, "output_all_frames", False) or m.arch != self.ARCH:
+            raise NotImplementedError("built: arch=unetmore -- the concat-conditioned network of configs/mine.yml (ScoreNet) and its "
+                                      "SPADE variant (SpadeScoreNet) -- and arch=unetmorepseudo3d without SPADE (Pseudo3dScoreNet), "
+                                      "all without output_all_frames (which fails in the reference itself: ncsnpp_more.py:384-385 "
+                                      "splits 15 channels into 6 + 15); the full Conv3d arch unetmore3d is not (SURVEY.md section 2)")
         # cond_emb: the time embedding is extended by an Embedding(2, ngf // 2) row chosen by cond_mask (ncsnpp_more.py:97-99,
         # :282-285); noise_in_cond, the schedule (linear / cosine) and the Gamma buffers: DdpmWrapper
         self.cond_emb = bool(getattr(m, "cond_emb", False))
         self._init_wrapper(m, self.d.sigma_begin, self.d.sigma_end, self.d.num_classes)
         if (self.cond_emb or self.noise_in_cond) and self.SPADE:
             raise NotImplementedError("cond_emb / noise_in_cond are built for the concat-conditioned network only")
-        self.program = build_program(self.d)
+        self.embed_dim = self._embed_dim()
+        self.program = self._build_program()
         if self.SPADE:     # the conditioning frames do not enter through the input (ncsnpp_more.py:519, :593-594)
             self.program[2]["cin"] = self.d.channels * self.d.num_frames
         self._load(state_dict, prefix + "unet.all_modules.")
@@ -225,6 +227,13 @@ class ScoreNet(DdpmWrapper):
         self._bound_next = 0
 
     # ------------------------------------------------------------------------------------------
+    def _build_program(self):
+        return build_program(self.d)
+
+    def _embed_dim(self):
+        """Width of the sinusoidal time embedding (``nf``, ncsnpp_more.py:50,80,274)."""
+        return self.d.ngf
+
     def _dev(self, t):
         return t.detach().to(device=self.device, dtype=torch.float32).contiguous()
 
@@ -301,7 +310,7 @@ class ScoreNet(DdpmWrapper):
     # ------------------------------------------------------------------------------------------
     def _embedding(self, labels):
         """get_timestep_embedding (models/better/layers.py:504-518) on the host, float32."""
-        dim = self.d.ngf
+        dim = self.embed_dim
         half = dim // 2
         emb = math.log(10000) / (half - 1)
         emb = torch.exp(torch.arange(half, dtype=torch.float32) * -emb)
@@ -320,7 +329,7 @@ class ScoreNet(DdpmWrapper):
         if not new:
             return
         R = len(new)
-        e = self._embedding([k[0] if self.cond_emb else k for k in new]).to(self.device).reshape(1, 1, R, self.d.ngf).contiguous()
+        e = self._embedding([k[0] if self.cond_emb else k for k in new]).to(self.device).reshape(1, 1, R, self.embed_dim).contiguous()
         w0, w1 = self.w[0], self.w[1]
         t = L.conv2d_nhwc(e, w0["w"], w0["co"], 1, 1, bias=w0["b"])                       # Linear(ngf -> 4ngf)
         t = L.conv2d_nhwc(t, w1["w"], w1["co"], 1, 1, bias=w1["b"], act_in=L.ACT_SILU)    # act -> Linear
@@ -606,11 +615,15 @@ class ScoreNet(DdpmWrapper):
 def build_score_network(config, state_dict, device="cuda", **kw):
     """``config.model.arch``: "unetmore" -> ScoreNet (the network the reference CLI hard-codes, city_sender.py:311-312), or
     SpadeScoreNet when ``config.model.spade`` (ncsnpp_more.py:730-733); "unet" -> UNetDDPM (reference models/unet.py,
-    upstream MCVD's name for it).  All plug into the same samplers."""
+    upstream MCVD's name for it); "unetmorepseudo3d" -> Pseudo3dScoreNet (the is3d / pseudo3d branches of ncsnpp_more.py with
+    models/better/layers3d.py).  All plug into the same samplers."""
     arch = getattr(config.model, "arch", "unetmore")
     if arch == "unet":
         from .unet_ddpm import UNetDDPM
         return UNetDDPM(config, state_dict, device=device)
+    if arch == "unetmorepseudo3d":
+        from .scorenet_pseudo3d import Pseudo3dScoreNet
+        return Pseudo3dScoreNet(config, state_dict, device=device, **kw)
     if getattr(config.model, "spade", False):
         from .scorenet_spade import SpadeScoreNet
         return SpadeScoreNet(config, state_dict, device=device, **kw)

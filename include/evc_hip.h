@@ -244,6 +244,24 @@ int evc_attention_ws_f32(const float* q, const float* k, const float* v, int ld_
 int evc_attention_f16x3_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out, int B,
                             int heads, int N, int D, float scale, const unsigned* bounds, float* ws, void* stream);
 
+/* ---- frame axis (pseudo-3-D score network, config.model.arch = unetmorepseudo3d) -----------------
+ * Video activations are x[b][n][pixel][c]: an NHWC tensor of B*N images, the N frames of a sample adjacent.  A per-frame Conv2d
+ * is then evc_conv2d_nhwc_f32 over B*N images; PseudoConv3d's Conv1d over the frames (reference models/better/layers3d.py:274,
+ * 294-297) is evc_conv2d_nhwc_f32 with KH = 3 (or 1), KW = 1 over B "images" of N rows x H*W columns; the 3-D GroupNorm's
+ * moments are evc_chan_stats_f32's with N times the pixel runs.  The three operations below have no 2-D counterpart. */
+/* nn.GroupNorm of AttnBlockpp1d on (B*H*W, C, N) (layers3d.py:89-90,107): per pixel, moments over (C / groups channels x N
+ * frames), biased variance, then * gamma[c] + beta[c].  y may alias x. */
+int evc_frame_group_norm_f32(const float* x, float* y, const float* gamma, const float* beta, int B, int N, int HW, int C,
+                             int groups, float eps, void* stream);
+/* Attention over the N <= 8 frames of one pixel (AttnBlockpp1d.forward, layers3d.py:112-118): q | k | v are channel ranges
+ * [0, C) | [C, 2C) | [2C, 3C) of qkv rows of stride ld_qkv; per (pixel, head) softmax_i(q_t . k_i * scale) applied to v. */
+int evc_frame_attention_f32(const float* qkv, int ld_qkv, float* out, int ld_out, int B, int N, int HW, int C, int heads,
+                            float scale, void* stream);
+/* The 1x1 "converter" convolution over the frame axis (reference models/better/ncsnpp_more.py:213-216,226-228,328-335,
+ * 344-351): y[b][m][j] = sum_n w[m][n] * x[b][n][j] + bias[m], j < inner = H*W*C (multiple of 4), N, M <= 8. */
+int evc_frame_mix_f32(const float* x, float* y, const float* w, const float* bias, int B, int N, int M, long long inner,
+                      void* stream);
+
 /* ---- sampler steps (elementwise, flat over n floats) ---------------------------------------- */
 /* DDPM ancestral step (models/__init__.py:289-330):
  *   x0 = k1*(x - k2*e); clip; x = c1*x0 + c2*x (+ sigma*noise when noise != NULL). */

@@ -871,3 +871,61 @@ def test_lpips_policy_metric_from_weight_files(tmp_path):
     assert [bool(m.accept(x, thr)) for x in v] == [True, True, True, False]
     torch.save(sd, tmp_path / "both.pth")                                       # one file holding everything
     np.testing.assert_array_equal(P.load_metric("lpips", str(tmp_path / "both.pth"), "cuda").values(pred.cuda(), gt.cuda()), v)
+
+
+# ---- frame-axis kernels of the pseudo-3-D score network (csrc/frames.hip) -------------------------------------------------
+
+def _video(seed, B, N, H, W, C):
+    """(B*N, H, W, C) with a sample's frames adjacent + the same data as the reference's per-pixel (B*H*W, C, N)."""
+    v = rnd(seed, B, N, H, W, C)
+    return v.reshape(B * N, H, W, C).cuda(), v.permute(0, 2, 3, 4, 1).reshape(B * H * W, C, N)
+
+
+@pytest.mark.parametrize("B,N,H,W,C,G", [(2, 5, 4, 4, 32, 8), (1, 3, 8, 8, 64, 16), (3, 7, 2, 2, 576, 32), (1, 1, 4, 4, 16, 4)])
+def test_frame_group_norm_against_torch(L, B, N, H, W, C, G):
+    """GroupNorm of AttnBlockpp1d (layers3d.py:89-90,107): per pixel over (C / G channels x N frames)."""
+    x, ref_in = _video(301, B, N, H, W, C)
+    gamma, beta = (1 + 0.1 * rnd(302, C)), 0.1 * rnd(303, C)
+    ref = F.group_norm(ref_in.double(), G, gamma.double(), beta.double(), 1e-6)          # (B*H*W, C, N)
+    y = L.frame_group_norm(x, N, gamma.cuda(), beta.cuda(), G, 1e-6)
+    got = y.cpu().reshape(B, N, H, W, C).permute(0, 2, 3, 4, 1).reshape(B * H * W, C, N)
+    assert rel(got, ref.float()) < 2e-6
+
+
+@pytest.mark.parametrize("B,N,H,W,C,heads", [(2, 5, 4, 4, 64, 2), (1, 3, 8, 8, 32, 1), (2, 7, 2, 2, 384, 2), (1, 8, 2, 2, 96, 3)])
+def test_frame_attention_against_torch(L, B, N, H, W, C, heads):
+    """AttnBlockpp1d's attention (layers3d.py:112-118): softmax over the frames of one pixel, per head."""
+    qkv, ref_in = _video(311, B, N, H, W, 3 * C)                                         # ref_in: (B*H*W, 3C, N)
+    D = C // heads
+    q, k, v = (ref_in[:, j * C:(j + 1) * C].double().reshape(-1, D, N) for j in range(3))
+    w = torch.softmax(torch.einsum("bct,bci->bti", q, k) * (int(D) ** (-0.5)), dim=-1)
+    ref = torch.einsum("bti,bci->bct", w, v).reshape(B * H * W, C, N)
+    o = L.frame_attention(qkv, N, C, heads)
+    got = o.cpu().reshape(B, N, H, W, C).permute(0, 2, 3, 4, 1).reshape(B * H * W, C, N)
+    assert rel(got, ref.float()) < 2e-6
+
+
+@pytest.mark.parametrize("B,N,M,H,W,C", [(2, 5, 3, 4, 4, 32), (1, 7, 5, 8, 8, 16), (3, 2, 2, 2, 2, 64), (1, 8, 1, 4, 4, 16)])
+def test_frame_mix_against_torch(L, B, N, M, H, W, C):
+    """The frame converters (ncsnpp_more.py:328-335,344-351): a 1x1 convolution over the frame axis."""
+    x, _ = _video(321, B, N, H, W, C)
+    w, b = rnd(322, M, N) / np.sqrt(N), 0.1 * rnd(323, M)
+    ref = torch.einsum("bnhwc,mn->bmhwc", x.cpu().double().reshape(B, N, H, W, C), w.double()) + b.double()[None, :, None, None, None]
+    y = L.frame_mix(x, N, w.cuda(), b.cuda())
+    assert y.shape == (B * M, H, W, C)
+    assert rel(y.cpu().reshape(B, M, H, W, C), ref.float()) < 2e-6
+
+
+def test_time_convolution_as_a_kx1_filter_over_the_frame_axis(L, arith):
+    """PseudoConv3d.time_conv (layers3d.py:274,294-297): Conv1d over the frames of each pixel = the 2-D convolution with a
+    3 x 1 filter over B "images" of N rows x H*W columns (zero padding along the frames only), SiLU on load, residual."""
+    B, N, H, W, C, Co = 2, 5, 4, 4, 32, 48
+    x, ref_in = _video(331, B, N, H, W, C)                                               # ref_in: (B*H*W, C, N)
+    res, res_ref = _video(332, B, N, H, W, Co)
+    w, b = rnd(333, Co, C, 3) / np.sqrt(3 * C), 0.1 * rnd(334, Co)
+    ref = (F.conv1d(F.silu(ref_in.double()), w.double(), b.double(), padding=1) + res_ref.double()) * 0.70710678
+    wp = L.conv_pack_weights(w[:, :, :, None].contiguous().cuda(), arith)
+    y = L.conv2d_nhwc(x.view(B, N, H * W, C), wp, Co, 3, 1, bias=b.cuda(), act_in=L.ACT_SILU,
+                      res=res.view(B, N, H * W, Co), out_scale=0.70710678)
+    got = y.cpu().reshape(B, N, H, W, Co).permute(0, 2, 3, 4, 1).reshape(B * H * W, Co, N)
+    assert rel(got, ref.float()) < 1e-5
