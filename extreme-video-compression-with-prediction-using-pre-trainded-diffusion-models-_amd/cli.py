@@ -197,7 +197,7 @@ def main(argv=None):
             else:
                 sys.exit(f"missing {pth} (pass --synthetic)")
     sd_d = D.broadcast_state_dict(sd_d, 0, device, world)
-    net = build_score_network(cfg, sd_d, device=device)     # model.arch: unetmore (default) | unet
+    net = build_score_network(cfg, sd_d, device=device)     # model.arch: unetmore (default, + spade) | unetmorepseudo3d | unet
     models = {q: ElicModel(D.broadcast_state_dict(sd_e.get(q), 0, device, world), device=device) for q in args.q}
 
     if os.path.exists(args.data_npy):

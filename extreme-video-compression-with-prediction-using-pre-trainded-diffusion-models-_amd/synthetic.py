@@ -18,7 +18,47 @@ from .scorenet import build_program, dims_from_config
 
 
 # ---- diffusion ------------------------------------------------------------------------------------
+def pseudo3d_param_shapes(config, prefix="unet.all_modules."):
+    """State-dict layout of NCSNpp with arch = unetmorepseudo3d (ncsnpp_more.py:70-247 is3d branches, layers3d.py)."""
+    from .scorenet_pseudo3d import build_program_3d
+    d = dims_from_config(config)
+    t = 4 * d.ngf * (d.num_frames + d.num_frames_cond)
+    out = []
+
+    def pconv(n, co, ci, k):
+        return [(n + ".space_conv.weight", (co, ci, k, k)), (n + ".space_conv.bias", (co,)),
+                (n + ".time_conv.weight", (co, co, k)), (n + ".time_conv.bias", (co,))]
+    for i, m in enumerate(build_program_3d(d)):
+        n = prefix + str(i)
+        k = m["kind"]
+        if k == "linear":
+            out += [(n + ".weight", (t, t // 4 if i == 0 else t)), (n + ".bias", (t,))]
+        elif k in ("conv_in", "conv_out"):
+            out += pconv(n, m["cout"], m["cin"], 3)
+        elif k == "mix":
+            out += [(n + ".weight", (m["frames_out"], m["frames"], 1, 1)), (n + ".bias", (m["frames_out"],))]
+        elif k == "res":
+            ci, co = m["cin"], m["cout"]
+            out += [(n + ".actnorm0.Dense_0.weight", (2 * ci, t)), (n + ".actnorm0.Dense_0.bias", (2 * ci,))]
+            out += pconv(n + ".Conv_0", co, ci, 3)
+            out += [(n + ".actnorm1.Dense_0.weight", (2 * co, t)), (n + ".actnorm1.Dense_0.bias", (2 * co,))]
+            out += pconv(n + ".Conv_1", co, co, 3)
+            if ci != co or m["up"] or m["down"]:
+                out += pconv(n + ".Conv_2", co, ci, 1)
+        elif k == "attn":
+            c = m["ch"]
+            for part in ("space_att", "time_att"):
+                out += [(f"{n}.{part}.GroupNorm_0.weight", (c,)), (f"{n}.{part}.GroupNorm_0.bias", (c,))]
+                for j in range(4):
+                    out += [(f"{n}.{part}.NIN_{j}.W", (c, c)), (f"{n}.{part}.NIN_{j}.b", (c,))]
+        elif k == "norm":
+            out += [(n + ".Norm_0.weight", (m["ch"],)), (n + ".Norm_0.bias", (m["ch"],))]
+    return out
+
+
 def diffusion_param_shapes(config, prefix="unet.all_modules."):
+    if getattr(config.model, "arch", "unetmore") == "unetmorepseudo3d":
+        return pseudo3d_param_shapes(config, prefix)
     d = dims_from_config(config)
     out = []
     t = 4 * d.ngf

@@ -228,3 +228,57 @@ def test_full_size_clip_decoder_two_chunks_at_a_rank_batch_vs_oracle():
     assert float((out[:, 2:7] - g1).abs().max()) < 2e-3              # fp32 sampler tolerance on [0,1] pixels
     # the second chunk was conditioned on generated frames 5, 6 (not on the key frames): it differs from the first
     assert float((out[:, 7:12] - out[:, 2:7]).abs().max()) > 1e-3
+
+
+def test_clip_decoder_with_the_pseudo3d_network_vs_oracle():
+    """The receiver loop with ``model.arch: unetmorepseudo3d`` (built through ``build_score_network`` from the synthetic
+    checkpoint generator, whose pseudo-3-D state-dict layout is the pinned oracle's): two key frames + two generated chunks,
+    the second conditioned on frames the first produced, against the oracle sampler + oracle pseudo-3-D network on the same
+    decoded conditioning frames and injected noise."""
+    import evc_amd  # noqa: F401
+    from evc_amd import sampler as S, synthetic
+    from evc_amd.config import default_config
+    from evc_amd.decoder import ClipDecoder
+    from evc_amd.elic import ElicModel
+    from evc_amd.scorenet import build_score_network
+    from evc_amd.scorenet_pseudo3d import Pseudo3dScoreNet
+    from oracle import samplers as OS, schedule as OSch, scorenet_pseudo3d as O3
+
+    cfg = default_config(32, 32, 64, subsample=3)
+    cfg.model.arch, cfg.model.ch_mult, cfg.model.num_res_blocks, cfg.model.attn_resolutions = "unetmorepseudo3d", [1, 2], 1, [32]
+    d_net = O3.Dims(ngf=32, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[32], n_head_channels=32, image_size=64)
+    p = synthetic.diffusion_state_dict(cfg, 23)
+    assert [k for k, _ in O3.param_shapes(d_net)] == list(p)
+    net = build_score_network(cfg, p)
+    assert isinstance(net, Pseudo3dScoreNet)
+    elic = ElicModel(synthetic.elic_state_dict(4))
+    dec = ClipDecoder(net, elic, cfg, S.get_sampler("DDPM"))
+    B, F = 2, 12
+    clips = torch.from_numpy(synthetic.make_clips(B, seed=7, frames=F, size=64).astype(np.float32) / 255)
+    mask = np.array([1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    key_strings, shape = [], None
+    for f in (0, 1):
+        enc = elic.compress(clips[:, f].cuda())
+        key_strings.append(enc["strings"])
+        shape = enc["shape"]
+    noise_log = []
+
+    def noise_fn(tag, shp):
+        tns = rnd(3000 + len(noise_log), *shp)
+        noise_log.append((tag, tns))
+        return tns.cuda()
+    out = dec.decode(mask, key_strings, shape, frames=F, noise_fn=noise_fn).cpu()
+    inits = [i for i, (tag, _) in enumerate(noise_log) if tag == "init"]
+    assert len(inits) == 2
+    sched = OSch.base_schedule()
+
+    def oracle_chunk(prev2, log):
+        cond = 2 * prev2.reshape(B, 6, 64, 64) - 1
+        steps = {tag: tns for tag, tns in log[1:]}
+        x = OS.ddpm(log[0][1].clone(), lambda xx, tt: O3.forward(p, d_net, xx, tt, cond=cond), sched,
+                    subsample_steps=3, noise_fn=lambda i, xx: steps[i])
+        return ((x[0] + 1) / 2).clamp(0, 1).reshape(B, 5, 3, 64, 64)
+    g1 = oracle_chunk(out[:, 0:2], noise_log[inits[0]:inits[1]])
+    assert float((out[:, 2:7] - g1).abs().max()) < 2e-3
+    g2 = oracle_chunk(out[:, 5:7], noise_log[inits[1]:])
+    assert float((out[:, 7:12] - g2).abs().max()) < 2e-3

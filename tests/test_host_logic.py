@@ -40,6 +40,27 @@ def test_module_program_matches_oracle_and_reference_counts():
     assert n == 262_133_775 - 0                                # parameter count of the reference net
 
 
+def test_pseudo3d_program_and_state_dict_layout_match_the_pinned_oracle():
+    """arch = unetmorepseudo3d: the host's module list and synthetic state-dict layout against oracle/scorenet_pseudo3d.py,
+    whose layout the reference's own ``load_state_dict`` accepted when the golden was made (make_goldens.py asserts equal
+    key order and shapes); at the reduced golden configuration and at the shipped size (ngf 192, 5 + 2 frames)."""
+    from oracle import scorenet_pseudo3d as O3
+    from evc_amd import scorenet_pseudo3d as P3
+    for kw in (dict(ngf=32, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16, 8], n_head_channels=32, image_size=16,
+                    num_frames=3, num_frames_cond=2), dict()):
+        d = O3.Dims(**kw)
+        cfg = C.default_config(d.ngf, d.n_head_channels, d.image_size)
+        cfg.model.arch, cfg.model.ch_mult, cfg.model.num_res_blocks = "unetmorepseudo3d", d.ch_mult, d.num_res_blocks
+        cfg.model.attn_resolutions = d.attn_resolutions
+        cfg.data.num_frames, cfg.data.num_frames_cond = d.num_frames, d.num_frames_cond
+        prog, ref = P3.build_program_3d(scorenet.dims_from_config(cfg)), O3.program(d)
+        assert [m["kind"].replace("conv_in", "conv3").replace("conv_out", "conv3") for m in prog] == [m["kind"] for m in ref]
+        for a, b in zip(prog, ref):
+            if a["kind"] == "res":
+                assert (a["cin"], a["cout"], a["up"], a["down"], a["frames"]) == (b["cin"], b["cout"], b["up"], b["down"], b["frames"])
+        assert synthetic.diffusion_param_shapes(cfg) == O3.param_shapes(d)
+
+
 def test_diffusion_checkpoint_layout_roundtrip(tmp_path):
     cfg = C.default_config(32, 32, 32)
     sd = synthetic.diffusion_state_dict(cfg, 3)
