@@ -5,14 +5,17 @@
 //                        pixel, affine (reference models/better/layers3d.py:89-90,107);
 //   * frame_attention  : the softmax attention of AttnBlockpp1d over the N frames of one pixel (layers3d.py:112-118);
 //   * frame_mix        : the 1x1 "converter" convolutions over the frame axis, N -> M frames
-//                        (reference models/better/ncsnpp_more.py:213-216,226-228,328-335,344-351).
+//                        (reference models/better/ncsnpp_more.py:213-216,226-228,328-335,344-351);
+//   * frame_taps       : the temporal taps of nn.Conv3d (arch = unetmore3d, layers3d.py:225-243) laid side by side along
+//                        the channels -- frames n - 1 | n | n + 1, zeros beyond a sample's first / last frame -- so that the
+//                        3 x 3 x 3 convolution is ONE 3 x 3 convolution with 3C input channels.
 //
 // Everything else of that network runs on the 2-D kernels: activations are kept frame-major inside a sample,
 // x[b][n][pixel][c] = an NHWC tensor of B*N images, so a per-frame Conv2d is an ordinary convolution over B*N images, the
 // Conv1d over the frames (PseudoConv3d.time_conv, layers3d.py:274,294-297) is a KH x 1 convolution over an "image" of
 // N rows x (H*W) columns, and the 3-D GroupNorm's moments are the per-frame moments read as N times as many pixel runs.
 //
-// All three are HBM-bound element / pixel-wise passes (N <= 8 frames): one read + one write of the tensor.
+// All four are HBM-bound element / pixel-wise passes (N <= 8 frames): one read + one write of the tensor.
 #include <hip/hip_runtime.h>
 #include "../../include/evc_hip.h"
 
@@ -169,7 +172,31 @@ __global__ __launch_bounds__(256) void frame_mix_kernel(const float* __restrict_
     }
 }
 
+// y[b][n][p][kt * C + c] = x[b][n + kt - 1][p][c] (0 outside the sample's frames), kt = 0, 1, 2; float4 along c.
+__global__ __launch_bounds__(256) void frame_taps_kernel(const float* __restrict__ x, float* __restrict__ y, int N, size_t HW,
+                                                         int C4, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        size_t r = i / C4;
+        const int kt = (int)(r % 3);
+        r /= 3;                                   // r = (b * N + n) * HW + p
+        const size_t p = r % HW, bn = r / HW;
+        const int n = (int)(bn % N) + kt - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n >= 0 && n < N) v = reinterpret_cast<const float4*>(x)[((bn + kt - 1) * HW + p) * C4 + c4];
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int evc_frame_taps_f32(const float* x, float* y, int B, int N, int HW, int C, void* stream) {
+    if (!x || !y || B <= 0 || N <= 0 || HW <= 0 || C <= 0 || (C & 3)) return EVC_EINVAL;
+    const size_t total = (size_t)B * N * HW * 3 * (C >> 2);
+    const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(frame_taps_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, N, (size_t)HW, C >> 2, total);
+    return hipGetLastError() == hipSuccess ? EVC_OK : EVC_ELAUNCH;
+}
 
 extern "C" int evc_frame_group_norm_f32(const float* x, float* y, const float* gamma, const float* beta, int B, int N,
                                         int HW, int C, int groups, float eps, void* stream) {

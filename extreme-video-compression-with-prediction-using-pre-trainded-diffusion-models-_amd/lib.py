@@ -132,6 +132,7 @@ HIP_SYMBOLS = {
     "evc_frame_group_norm_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_float, c_void_p]),
     "evc_frame_attention_f32": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_int] * 5 + [c_float, c_void_p]),
     "evc_frame_mix_f32": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_longlong, c_void_p]),
+    "evc_frame_taps_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "evc_ddpm_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong] + [c_float] * 5 + [c_int, c_void_p]),
     "evc_ddim_step_f32": (c_int, [c_void_p, c_void_p, c_longlong] + [c_float] * 4 + [c_int, c_void_p]),
     "evc_axpy_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_void_p]),
@@ -695,6 +696,15 @@ def frame_mix(x, N, w, bias):
     y = torch.empty((B * M, H, W, C), device=x.device, dtype=torch.float32)
     _check(hip_lib().evc_frame_mix_f32(fptr(x), fptr(y), fptr(w), fptr(bias), B, N, M, H * W * C, stream_ptr()),
            "evc_frame_mix_f32")
+    return y
+
+
+def frame_taps(x, N):
+    """Frames n - 1 | n | n + 1 side by side along the channels (zeros beyond a sample's frames): (B*N, H, W, C) -> (B*N, H, W, 3C)."""
+    BN, H, W, C = x.shape
+    assert BN % N == 0 and x.is_contiguous()
+    y = torch.empty((BN, H, W, 3 * C), device=x.device, dtype=torch.float32)
+    _check(hip_lib().evc_frame_taps_f32(fptr(x), fptr(y), BN // N, N, H * W, C, stream_ptr()), "evc_frame_taps_f32")
     return y
 
 

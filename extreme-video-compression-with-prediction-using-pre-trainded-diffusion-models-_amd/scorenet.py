@@ -187,9 +187,9 @@ class ScoreNet(DdpmWrapper):
         m = config.model
         if bool(getattr(m, "spade", False)) != self.SPADE or getattr(m, "output_all_frames", False) or m.arch != self.ARCH:
             raise NotImplementedError("built: arch=unetmore -- the concat-conditioned network of configs/mine.yml (ScoreNet) and its "
-                                      "SPADE variant (SpadeScoreNet) -- and arch=unetmorepseudo3d without SPADE (Pseudo3dScoreNet), "
-                                      "all without output_all_frames (which fails in the reference itself: ncsnpp_more.py:384-385 "
-                                      "splits 15 channels into 6 + 15); the full Conv3d arch unetmore3d is not (SURVEY.md section 2)")
+                                      "SPADE variant (SpadeScoreNet) -- and arch=unetmorepseudo3d / unetmore3d without SPADE "
+                                      "(Pseudo3dScoreNet / Conv3dScoreNet), all without output_all_frames (which fails in the "
+                                      "reference itself: ncsnpp_more.py:384-385 splits 15 channels into 6 + 15)")
         # cond_emb: the time embedding is extended by an Embedding(2, ngf // 2) row chosen by cond_mask (ncsnpp_more.py:97-99,
         # :282-285); noise_in_cond, the schedule (linear / cosine) and the Gamma buffers: DdpmWrapper
         self.cond_emb = bool(getattr(m, "cond_emb", False))
@@ -615,15 +615,15 @@ class ScoreNet(DdpmWrapper):
 def build_score_network(config, state_dict, device="cuda", **kw):
     """``config.model.arch``: "unetmore" -> ScoreNet (the network the reference CLI hard-codes, city_sender.py:311-312), or
     SpadeScoreNet when ``config.model.spade`` (ncsnpp_more.py:730-733); "unet" -> UNetDDPM (reference models/unet.py,
-    upstream MCVD's name for it); "unetmorepseudo3d" -> Pseudo3dScoreNet (the is3d / pseudo3d branches of ncsnpp_more.py with
-    models/better/layers3d.py).  All plug into the same samplers."""
+    upstream MCVD's name for it); "unetmorepseudo3d" / "unetmore3d" -> Pseudo3dScoreNet / Conv3dScoreNet (the is3d / pseudo3d
+    branches of ncsnpp_more.py with models/better/layers3d.py).  All plug into the same samplers."""
     arch = getattr(config.model, "arch", "unetmore")
     if arch == "unet":
         from .unet_ddpm import UNetDDPM
         return UNetDDPM(config, state_dict, device=device)
-    if arch == "unetmorepseudo3d":
-        from .scorenet_pseudo3d import Pseudo3dScoreNet
-        return Pseudo3dScoreNet(config, state_dict, device=device, **kw)
+    if arch in ("unetmorepseudo3d", "unetmore3d"):
+        from .scorenet_pseudo3d import Conv3dScoreNet, Pseudo3dScoreNet
+        return (Conv3dScoreNet if arch == "unetmore3d" else Pseudo3dScoreNet)(config, state_dict, device=device, **kw)
     if getattr(config.model, "spade", False):
         from .scorenet_spade import SpadeScoreNet
         return SpadeScoreNet(config, state_dict, device=device, **kw)

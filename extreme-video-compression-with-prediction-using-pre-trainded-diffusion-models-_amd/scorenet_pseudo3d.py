@@ -297,3 +297,43 @@ class Pseudo3dScoreNet(ScoreNet):
         if taps is not None:
             taps[i] = out.t[..., :co].reshape(B, M, Hh, Wh, co).permute(0, 4, 1, 2, 3).reshape(B, co * M, Hh, Wh)
         return res
+
+
+class Conv3dScoreNet(Pseudo3dScoreNet):
+    """``arch: unetmore3d``: the same network with ``MyConv3d`` (nn.Conv3d 3x3x3 / 1x1x1, layers3d.py:225-254) where the
+    pseudo-3-D variant has its Conv2d -> SiLU -> Conv1d pairs (ncsnpp_more.py:104-106, layerspp.py:569-571).
+
+    A 3x3x3 convolution over (N, H, W) is ONE 3x3 convolution over B*N images whose input channels are the activated frames
+    n - 1 | n | n + 1 side by side (``evc_frame_taps_f32``: zeros beyond a sample's first / last frame -- which is why the
+    act-norm is materialised first instead of fused into the load: a missing frame must stay zero), with the weight
+    (Co, Ci, kt, kh, kw) read as (Co, kt*Ci + ci, kh, kw).  The 1x1x1 convolution is a 1x1 convolution over B*N images."""
+
+    ARCH = "unetmore3d"
+
+    def _load_pconv(self, e, key, n, g, pad_ci=None, pad_mid=None):
+        w = g(n + ".conv.weight")                                  # (Co, Ci, k, k, k)
+        co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+        cp = ci if pad_ci is None else pad_ci
+        w2 = torch.zeros((co, k, cp, k, k), dtype=torch.float32)
+        w2[:, :, :ci] = w.detach().float().permute(0, 2, 1, 3, 4)
+        e[key + "s"] = self._pack_conv(w2.reshape(co, k * cp, k, k))
+        e[key + "sb"] = self._dev(g(n + ".conv.bias"))
+
+    def _pconv(self, e, key, src, co, k, N, src1=None, coef=None, act_in=L.ACT_NONE, res=None, out_scale=1.0):
+        BN, H, W, C0 = src.shape
+        if k == 3:
+            C1 = 0 if src1 is None else src1.shape[3]
+            if coef is not None or src1 is not None:
+                act = torch.empty((BN, H, W, C0 + C1), device=self.device, dtype=torch.float32)
+                L.affine_act(src, coef, act_in, out=L.Cols(act, 0, C0))
+                if src1 is not None:
+                    L.affine_act(src1, coef, act_in, out=L.Cols(act, C0, C1), coef_col=C0)
+                src = act
+            src, src1, coef, act_in = L.frame_taps(src, N), None, None, L.ACT_NONE
+        out = torch.zeros((BN, H, W, _pad16(co)), device=self.device, dtype=torch.float32) if co % 16 else None
+        r = L.conv2d_nhwc(src, e[key + "s"], co, k, k, bias=e[key + "sb"], src1=src1, coef=coef, act_in=act_in, res=res,
+                          out_scale=out_scale, out=out, want_stats=(out is None))
+        if out is not None:
+            return _Video(r, N)
+        y, st = r
+        return _Video(y, N, st.view(BN // N, N * st.shape[1], st.shape[2], 2))    # per-image moments = N times the pixel runs

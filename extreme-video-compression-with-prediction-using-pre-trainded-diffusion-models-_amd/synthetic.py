@@ -19,13 +19,15 @@ from .scorenet import build_program, dims_from_config
 
 # ---- diffusion ------------------------------------------------------------------------------------
 def pseudo3d_param_shapes(config, prefix="unet.all_modules."):
-    """State-dict layout of NCSNpp with arch = unetmorepseudo3d (ncsnpp_more.py:70-247 is3d branches, layers3d.py)."""
+    """State-dict layout of NCSNpp with arch = unetmorepseudo3d / unetmore3d (ncsnpp_more.py:70-247 is3d branches, layers3d.py)."""
     from .scorenet_pseudo3d import build_program_3d
     d = dims_from_config(config)
     t = 4 * d.ngf * (d.num_frames + d.num_frames_cond)
     out = []
 
     def pconv(n, co, ci, k):
+        if config.model.arch == "unetmore3d":            # MyConv3d (layers3d.py:225-254)
+            return [(n + ".conv.weight", (co, ci, k, k, k)), (n + ".conv.bias", (co,))]
         return [(n + ".space_conv.weight", (co, ci, k, k)), (n + ".space_conv.bias", (co,)),
                 (n + ".time_conv.weight", (co, co, k)), (n + ".time_conv.bias", (co,))]
     for i, m in enumerate(build_program_3d(d)):
@@ -57,7 +59,7 @@ def pseudo3d_param_shapes(config, prefix="unet.all_modules."):
 
 
 def diffusion_param_shapes(config, prefix="unet.all_modules."):
-    if getattr(config.model, "arch", "unetmore") == "unetmorepseudo3d":
+    if getattr(config.model, "arch", "unetmore") in ("unetmorepseudo3d", "unetmore3d"):
         return pseudo3d_param_shapes(config, prefix)
     d = dims_from_config(config)
     out = []

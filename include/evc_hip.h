@@ -248,7 +248,7 @@ int evc_attention_f16x3_f32(const float* q, const float* k, const float* v, int 
  * Video activations are x[b][n][pixel][c]: an NHWC tensor of B*N images, the N frames of a sample adjacent.  A per-frame Conv2d
  * is then evc_conv2d_nhwc_f32 over B*N images; PseudoConv3d's Conv1d over the frames (reference models/better/layers3d.py:274,
  * 294-297) is evc_conv2d_nhwc_f32 with KH = 3 (or 1), KW = 1 over B "images" of N rows x H*W columns; the 3-D GroupNorm's
- * moments are evc_chan_stats_f32's with N times the pixel runs.  The three operations below have no 2-D counterpart. */
+ * moments are evc_chan_stats_f32's with N times the pixel runs.  The operations below have no 2-D counterpart. */
 /* nn.GroupNorm of AttnBlockpp1d on (B*H*W, C, N) (layers3d.py:89-90,107): per pixel, moments over (C / groups channels x N
  * frames), biased variance, then * gamma[c] + beta[c].  y may alias x. */
 int evc_frame_group_norm_f32(const float* x, float* y, const float* gamma, const float* beta, int B, int N, int HW, int C,
@@ -261,6 +261,12 @@ int evc_frame_attention_f32(const float* qkv, int ld_qkv, float* out, int ld_out
  * 344-351): y[b][m][j] = sum_n w[m][n] * x[b][n][j] + bias[m], j < inner = H*W*C (multiple of 4), N, M <= 8. */
 int evc_frame_mix_f32(const float* x, float* y, const float* w, const float* bias, int B, int N, int M, long long inner,
                       void* stream);
+
+/* The temporal taps of nn.Conv3d (config.model.arch = unetmore3d, reference models/better/layers3d.py:225-243) side by side
+ * along the channels: y[b][n][pixel][kt*C + c] = x[b][n + kt - 1][pixel][c], zeros beyond a sample's first / last frame,
+ * kt = 0, 1, 2.  The 3 x 3 x 3 convolution is then evc_conv2d_nhwc_f32 (KH = KW = 3) over B*N images with 3C input channels
+ * and the weight (Co, Ci, kt, kh, kw) read as (Co, kt*Ci + ci, kh, kw).  x must already be activated (zeros stay zeros). */
+int evc_frame_taps_f32(const float* x, float* y, int B, int N, int HW, int C, void* stream);
 
 /* ---- sampler steps (elementwise, flat over n floats) ---------------------------------------- */
 /* DDPM ancestral step (models/__init__.py:289-330):

@@ -458,7 +458,13 @@ def pseudo3d_dims():
                 channels=3, num_frames=3, num_frames_cond=2)
 
 
-def gen_forward_pseudo3d():
+def gen_forward_conv3d():
+    """``model.arch: unetmore3d``: the same network with nn.Conv3d (3x3x3 / 1x1x1, layers3d.py:225-254) in place of the
+    pseudo-3-D convolution pairs."""
+    gen_forward_pseudo3d(arch="unetmore3d", name="forward_conv3d", seed=96)
+
+
+def gen_forward_pseudo3d(arch="unetmorepseudo3d", name="forward_pseudo3d", seed=91):
     """``model.arch: unetmorepseudo3d`` (ncsnpp_more.py:40-51,101-122 + models/better/layers3d.py), reduced size: every 3x3 /
     1x1 convolution a per-frame Conv2d -> SiLU -> Conv1d over the frames, GroupNorm over (C / G, N, H, W), space-then-time
     attention, and the 1x1 "converters" from 5 frames (3 + 2 conditioning) to 3.  Outputs at three labels + strided samples
@@ -466,11 +472,11 @@ def gen_forward_pseudo3d():
     from models.better.ncsnpp_more import UNetMore_DDPM
     from oracle import scorenet_pseudo3d as O3
     d = pseudo3d_dims()
-    cfg = ref_config(d.ngf, d.n_head_channels, d.image_size, arch="unetmorepseudo3d", ch_mult=d.ch_mult,
+    cfg = ref_config(d.ngf, d.n_head_channels, d.image_size, arch=arch, ch_mult=d.ch_mult,
                      num_res_blocks=d.num_res_blocks, attn_resolutions=d.attn_resolutions)
     cfg.data.num_frames, cfg.data.num_frames_cond, cfg.data.num_frames_future = d.num_frames, d.num_frames_cond, 0
     net = UNetMore_DDPM(cfg).eval()
-    p = O3.seeded_params(d, 91)
+    p = O3.seeded_params(d, seed, arch=arch)
     own = dict(net.named_parameters())
     assert set(own) == set(p), sorted(set(own) ^ set(p))[:8]
     assert [k for k in own] == [k for k in p], "state_dict order"
@@ -499,7 +505,7 @@ def gen_forward_pseudo3d():
         samples[f"tap{idx}"] = flat[::stride][:512].clone()
         samples[f"tapstat{idx}"] = torch.stack([t.mean(), t.std()])
         samples[f"tapshape{idx}"] = torch.tensor(t.shape)
-    save("forward_pseudo3d", out_t0=o0, out_t430_7=o1, out_tm05=o2, **samples)
+    save(name, out_t0=o0, out_t430_7=o1, out_tm05=o2, **samples)
 
 
 if __name__ == "__main__":
@@ -511,7 +517,7 @@ if __name__ == "__main__":
                 samplers=gen_samplers, sampler_options=gen_sampler_options, sampler_gamma=gen_sampler_gamma, model_options=gen_model_options, lpips_lin=gen_lpips_lin,
                 forward_full=gen_forward_full, forward_full_b9=gen_forward_full_b9,
                 traj_full=gen_traj_full, traj_fpndm_full=gen_traj_fpndm_full, traj_ddim_full=gen_traj_ddim_full, unet_ddpm=gen_unet_ddpm, forward_spade=gen_forward_spade,
-                forward_pseudo3d=gen_forward_pseudo3d)
+                forward_pseudo3d=gen_forward_pseudo3d, forward_conv3d=gen_forward_conv3d)
     for name, fn in gens.items():
         if a.only and name != a.only:
             continue

@@ -929,3 +929,22 @@ def test_time_convolution_as_a_kx1_filter_over_the_frame_axis(L, arith):
                       res=res.view(B, N, H * W, Co), out_scale=0.70710678)
     got = y.cpu().reshape(B, N, H, W, Co).permute(0, 2, 3, 4, 1).reshape(B * H * W, Co, N)
     assert rel(got, ref.float()) < 1e-5
+
+
+def test_conv3d_as_frame_taps_plus_one_3x3_convolution(L, arith):
+    """nn.Conv3d 3x3x3 over (N, H, W) (MyConv3d, layers3d.py:225-243) = evc_frame_taps_f32 (frames n - 1 | n | n + 1 side by
+    side along the channels, zeros beyond a sample's frames) + ONE 3x3 convolution with 3C input channels and the weight read
+    as (Co, kt*Ci + ci, kh, kw), against torch.nn.functional.conv3d."""
+    B, N, H, W, C, Co = 2, 4, 6, 6, 16, 32
+    v = rnd(341, B, N, H, W, C)
+    x = v.reshape(B * N, H, W, C).cuda()
+    w, b = rnd(342, Co, C, 3, 3, 3) / np.sqrt(27 * C), 0.1 * rnd(343, Co)
+    ref = F.conv3d(v.permute(0, 4, 1, 2, 3).double(), w.double(), b.double(), padding=1)        # (B, Co, N, H, W)
+    taps = L.frame_taps(x, N)
+    assert taps.shape == (B * N, H, W, 3 * C)
+    t5 = taps.cpu().reshape(B, N, H, W, 3, C)
+    assert torch.equal(t5[:, :, :, :, 1], v) and torch.equal(t5[:, 1:, :, :, 0], v[:, :-1]) and torch.equal(t5[:, :-1, :, :, 2], v[:, 1:])
+    assert float(t5[:, 0, :, :, 0].abs().max()) == 0 and float(t5[:, -1, :, :, 2].abs().max()) == 0
+    w2 = w.permute(0, 2, 1, 3, 4).reshape(Co, 3 * C, 3, 3).contiguous().cuda()
+    y = L.conv2d_nhwc(taps, L.conv_pack_weights(w2, arith), Co, 3, 3, bias=b.cuda())
+    assert rel(y.cpu().reshape(B, N, H, W, Co).permute(0, 4, 1, 2, 3), ref.float()) < 1e-5

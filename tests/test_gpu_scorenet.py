@@ -692,29 +692,33 @@ def test_spade_scorenet_full_size_against_oracle():
     assert rel(out, ref.numpy()) < 2e-4
 
 
-def build_pseudo3d():
+ARCHS_3D = [("unetmorepseudo3d", "forward_pseudo3d", 91), ("unetmore3d", "forward_conv3d", 96)]
+
+
+def build_pseudo3d(arch="unetmorepseudo3d", seed=91):
     import evc_amd  # noqa: F401
     from evc_amd.scorenet import build_score_network
     from oracle import scorenet_pseudo3d as O3
     from test_oracle_goldens import pseudo3d_dims
     d = pseudo3d_dims()
     cfg = make_config(d.ngf, d.n_head_channels, d.image_size)
-    cfg.model.arch, cfg.model.ch_mult, cfg.model.num_res_blocks = "unetmorepseudo3d", d.ch_mult, d.num_res_blocks
+    cfg.model.arch, cfg.model.ch_mult, cfg.model.num_res_blocks = arch, d.ch_mult, d.num_res_blocks
     cfg.model.attn_resolutions = d.attn_resolutions
     cfg.data.num_frames, cfg.data.num_frames_cond = d.num_frames, d.num_frames_cond
-    p = O3.seeded_params(d, 91)
+    p = O3.seeded_params(d, seed, arch=arch)
     return build_score_network(cfg, p), d, p, O3
 
 
-def test_pseudo3d_network_against_reference_goldens():
-    """``arch: unetmorepseudo3d`` (ncsnpp_more.py is3d / pseudo3d branches + models/better/layers3d.py) on the HIP kernels:
-    outputs at integer, mixed and fractional labels and the output of EVERY module of ``all_modules`` -- pseudo-3-D
-    convolutions, res-blocks with the 3-D AdaGN, space + time attention blocks, the frame converters -- against the
+@pytest.mark.parametrize("arch,name,seed", ARCHS_3D)
+def test_pseudo3d_network_against_reference_goldens(arch, name, seed):
+    """``arch: unetmorepseudo3d`` / ``unetmore3d`` (ncsnpp_more.py is3d / pseudo3d branches + models/better/layers3d.py) on the
+    HIP kernels: outputs at integer, mixed and fractional labels and the output of EVERY module of ``all_modules`` -- pseudo-3-D
+    (or Conv3d) convolutions, res-blocks with the 3-D AdaGN, space + time attention blocks, the frame converters -- against the
     reference's own (tests/golden/make_goldens.py::gen_forward_pseudo3d, forward hooks), fp32 tolerance 1e-4 (SURVEY.md 8c)."""
-    from evc_amd.scorenet_pseudo3d import Pseudo3dScoreNet
-    g = golden("forward_pseudo3d")
-    net, d, p, O3 = build_pseudo3d()
-    assert isinstance(net, Pseudo3dScoreNet)
+    from evc_amd.scorenet_pseudo3d import Conv3dScoreNet, Pseudo3dScoreNet
+    g = golden(name)
+    net, d, p, O3 = build_pseudo3d(arch, seed)
+    assert type(net) is (Conv3dScoreNet if arch == "unetmore3d" else Pseudo3dScoreNet)
     x, cond = rnd(92, 2, 9, 16, 16).cuda(), rnd(93, 2, 6, 16, 16).cuda()
     for key, lab in (("out_t0", [0, 0]), ("out_tm05", [-0.5, -0.5])):
         out = net(x, torch.tensor(lab), cond=cond)
@@ -741,21 +745,22 @@ def test_pseudo3d_network_against_reference_goldens():
         mean, std = g[f"tapstat{idx}"]
         assert abs(float(t.std()) - float(std)) < 1e-4 * float(std), (idx, m)
         kinds[m["kind"]] = kinds.get(m["kind"], 0) + 1
-    print(f"pseudo-3-D: {sum(kinds.values())} module outputs checked, worst relative error {worst:.2e}")
+    print(f"{arch}: {sum(kinds.values())} module outputs checked, worst relative error {worst:.2e}")
     assert kinds == dict(conv3=2, res=10, attn=5, mix=5), kinds
 
 
-def test_pseudo3d_network_in_the_sampler_against_the_oracle():
-    """The pseudo-3-D network plugs into the same sampling loop: a 10-step DDPM chunk (11 forwards) with injected noise
+@pytest.mark.parametrize("arch,name,seed", ARCHS_3D)
+def test_pseudo3d_network_in_the_sampler_against_the_oracle(arch, name, seed):
+    """The pseudo-3-D (or Conv3d) network plugs into the same sampling loop: a 10-step DDPM chunk (11 forwards) with injected noise
     against oracle/samplers.ddpm over oracle/scorenet_pseudo3d.forward (same weights, same draws)."""
     from evc_amd import sampler
     from oracle import samplers as OS, schedule as OSch
-    net, d, p, O3 = build_pseudo3d()
+    net, d, p, O3 = build_pseudo3d(arch, seed)
     B = 2
     xT, cond = rnd(94, B, 9, 16, 16), rnd(95, B, 6, 16, 16).clamp(-1, 1)
     noises = [rnd(200 + k, B, 9, 16, 16) for k in range(10)]
     out = sampler.ddpm_sampler(xT.cuda(), net, cond=cond.cuda(), subsample_steps=10, denoise=True, clip_before=True,
                                final_only=True, noise_fn=lambda i, x: noises[i])[0].cpu()
-    ref = OS.ddpm(xT.clone(), lambda x, t: O3.forward(p, d, x, t, cond=cond), OSch.base_schedule(), subsample_steps=10,
+    ref = OS.ddpm(xT.clone(), lambda x, t: O3.forward(p, d, x, t, cond=cond, arch=arch), OSch.base_schedule(), subsample_steps=10,
                   noise_fn=lambda i, x: noises[i])[0]
     assert rel(out, ref.numpy()) < 2e-4

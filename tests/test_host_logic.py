@@ -59,6 +59,8 @@ def test_pseudo3d_program_and_state_dict_layout_match_the_pinned_oracle():
             if a["kind"] == "res":
                 assert (a["cin"], a["cout"], a["up"], a["down"], a["frames"]) == (b["cin"], b["cout"], b["up"], b["down"], b["frames"])
         assert synthetic.diffusion_param_shapes(cfg) == O3.param_shapes(d)
+        cfg.model.arch = "unetmore3d"                  # nn.Conv3d in place of the pseudo-3-D pairs, same module list
+        assert synthetic.diffusion_param_shapes(cfg) == O3.param_shapes(d, arch="unetmore3d")
 
 
 def test_diffusion_checkpoint_layout_roundtrip(tmp_path):

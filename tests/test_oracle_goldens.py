@@ -252,19 +252,20 @@ def pseudo3d_dims():
                 channels=3, num_frames=3, num_frames_cond=2)
 
 
-def test_pseudo3d_scorenet_oracle_matches_reference_goldens():
-    """``model.arch: unetmorepseudo3d`` (ncsnpp_more.py is3d / pseudo3d branches + models/better/layers3d.py): the oracle's
-    forward at integer, mixed and fractional labels and the output of every module of ``all_modules`` (pseudo-3-D
-    convolutions, 3-D AdaGN res-blocks, space + time attention, frame converters) against the reference's own."""
+@pytest.mark.parametrize("arch,name,seed", [("unetmorepseudo3d", "forward_pseudo3d", 91), ("unetmore3d", "forward_conv3d", 96)])
+def test_pseudo3d_scorenet_oracle_matches_reference_goldens(arch, name, seed):
+    """``model.arch: unetmorepseudo3d`` / ``unetmore3d`` (ncsnpp_more.py is3d / pseudo3d branches + models/better/layers3d.py):
+    the oracle's forward at integer, mixed and fractional labels and the output of every module of ``all_modules`` (pseudo-3-D
+    or Conv3d convolutions, 3-D AdaGN res-blocks, space + time attention, frame converters) against the reference's own."""
     from oracle import scorenet_pseudo3d as O3
-    g = golden("forward_pseudo3d")
+    g = golden(name)
     d = pseudo3d_dims()
-    p = O3.seeded_params(d, 91)
+    p = O3.seeded_params(d, seed, arch=arch)
     x, cond = rnd(92, 2, 9, 16, 16), rnd(93, 2, 6, 16, 16)
     for key, lab in (("out_t0", [0, 0]), ("out_tm05", [-0.5, -0.5])):
-        assert _rel(O3.forward(p, d, x, torch.tensor(lab), cond=cond).numpy(), g[key]) < 2e-5, key
+        assert _rel(O3.forward(p, d, x, torch.tensor(lab), cond=cond, arch=arch).numpy(), g[key]) < 2e-5, key
     taps = {}
-    out = O3.forward(p, d, x, torch.tensor([430, 7]), cond=cond, taps=taps)
+    out = O3.forward(p, d, x, torch.tensor([430, 7]), cond=cond, taps=taps, arch=arch)
     assert _rel(out.numpy(), g["out_t430_7"]) < 2e-5
     mods = O3.program(d)
     kinds = {}
