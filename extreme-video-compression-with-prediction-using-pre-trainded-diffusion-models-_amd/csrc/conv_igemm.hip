@@ -79,6 +79,7 @@ struct ConvK {
     // computed by tail_splits workgroups each (tail_sps K-steps per workgroup) that write raw partial sums to slabs of
     // tail_rows rows [tail_splits][tail_rows][Co]; blockIdx.x >= tail_first enumerates (tile, split) pairs.
     int tail_first, tail_splits, tail_sps, tail_rows;
+    int cut_chunk;   // conv_wide_kernel with splits == 2: piece 0 = chunks [0, cut_chunk), piece 1 = the rest (0 = equal pieces)
     // Fused 1x1 operand (row-reuse f16x3 kernel only): out += conv1x1(x2; w2).  x2 is a raw tensor (two sources like src),
     // scaled from its element bound like in_bound; its products are accumulated FIRST, the accumulators are then rescaled
     // by the exact power of two between the two operands' scales and the 3x3 K loop continues into them.
@@ -1421,8 +1422,11 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(ConvK p) {
     const int n0 = blockIdx.y * BN;
     const int split = tail ? (int)blockIdx.x - p.tail_first - tq * p.tail_splits : (int)blockIdx.z;
     const int sps = tail ? p.tail_sps : p.steps_per_split;                      // multiple of 9 (host)
-    const int c_begin = min(p.nchunk, split * (sps / 9));
-    const int c_end = min(p.nchunk, c_begin + sps / 9);
+    // unequal pieces (ConvK::cut_chunk): a grid of T < 256 tiles leaves 256 - T CUs idle; cutting every tile into a long piece
+    // (dispatched first: blockIdx.z = 0) and a short one lets the idle CUs -- and the CUs that finish a short piece -- take
+    // the short pieces while the long ones run
+    const int c_begin = p.cut_chunk ? (split ? p.cut_chunk : 0) : min(p.nchunk, split * (sps / 9));
+    const int c_end = p.cut_chunk ? (split ? p.nchunk : p.cut_chunk) : min(p.nchunk, c_begin + sps / 9);
 
     const int bimg = m0 / p.HW;                        // the tile lies inside ONE image (HW % 256 == 0)
     const int y0 = (m0 - bimg * p.HW) / W;
@@ -2013,7 +2017,9 @@ static int conv_validate(const evc_conv_args* a) {
 // write + combine traffic and no half-empty tiles (A/B: 8x8 768->768 58 -> 69 TFLOP/s; on mid-size grids such
 // as 32x32 576->576 the smaller tile loses, 92 -> 84, so it is not used there).
 struct TileCfg { int tm, tn, bm, bn; long long tiles; int splits; int reuse; int wide; int steps_per_split;
-                 int tail_first, tail_tiles, tail_splits, tail_sps; };    // K-split tail: pixel tiles >= tail_first (0 tiles = none)
+                 int tail_first, tail_tiles, tail_splits, tail_sps;       // K-split tail: pixel tiles >= tail_first (0 tiles = none)
+                 int cut_chunk; };                                        // wide kernel, 2 UNEQUAL K pieces: [0, cut) | [cut, nchunk); 0 = equal
+static int g_wide_cut = 1;     // run-time option "wide_cut": the unequal 2-way K split of conv_wide_kernel on grids of 129..255 workgroups
 static int g_tail_split = EVC_CONV_TAIL;   // run-time option "tail_split"
 static int g_wide_tiles = EVC_SPLIT_WIDE_TILES;   // harness A/B switch for the 256-pixel row-reuse tiles
 static int g_no_reuse = 0;     // same: lets the harness A/B the row-reuse kernel inside one binary
@@ -2121,6 +2127,7 @@ static bool wide_ok(const evc_conv_args* a) {
 static TileCfg conv_tile_cfg(const evc_conv_args* a) {
     TileCfg c;
     c.wide = 0;
+    c.cut_chunk = 0;
     const long long M = (long long)a->B * a->H * a->W;
     const int CoPad = evc_conv_co_pad(a->Co);
     c.tn = pick_tn(CoPad);
@@ -2206,6 +2213,22 @@ static TileCfg conv_tile_cfg(const evc_conv_args* a) {
                 c.tail_first = 0; c.tail_tiles = 0; c.tail_splits = 1; c.tail_sps = 0;
                 c.splits = (nchunk + cps - 1) / cps;
                 c.steps_per_split = cps * 9;
+                // 129..255 unsplit workgroups (64 x 64 x 192 channels at B = 9: 144): two UNEQUAL pieces per tile.  The long
+                // pieces start first on `wgs` CUs; the short ones fill the 256 - wgs idle CUs in r = ceil(wgs / (256 - wgs))
+                // turns.  Same cost model: long = 23 000 + 13 900 (nchunk - s), short turns = r (23 000 + 13 900 s), + combine.
+                if (g_wide_cut && best_s == 1 && wgs > 128 && nchunk >= 6) {
+                    const long long idle = 256 - wgs, r = (wgs + idle - 1) / idle;
+                    const double slab_mb = 2.0 * M * a->Co * 4.0 / 1e6;
+                    const double comb = 2.0 * 2000.0 * (5.0 + slab_mb / 4.0);
+                    int cut = 0;
+                    double t_cut = best_t * 0.95;                       // must beat the unsplit grid by 5 % on the model
+                    for (int sh = 1; sh <= nchunk / 2; ++sh) {
+                        const double tl = 23000.0 + 13900.0 * (nchunk - sh), ts = (double)r * (23000.0 + 13900.0 * sh);
+                        const double t = (tl > ts ? tl : ts) + comb;
+                        if (t < t_cut) { t_cut = t; cut = nchunk - sh; }
+                    }
+                    if (cut > 0) { c.splits = 2; c.cut_chunk = cut; c.steps_per_split = cut * 9; }
+                }
                 return c;
             }
         }
@@ -2227,6 +2250,7 @@ extern "C" int evc_conv_set_option(const char* name, int value) {
     if (is("tail_split")) { g_tail_split = value; return EVC_OK; }
     if (is("wide256")) { g_wide256 = value; return EVC_OK; }
     if (is("wide_mid")) { g_wide_mid = value; return EVC_OK; }
+    if (is("wide_cut")) { g_wide_cut = value; return EVC_OK; }
     return EVC_EINVAL;
 }
 
@@ -2452,6 +2476,7 @@ static int conv2d_impl(const evc_conv_args* a, float* ws, void* stream, hipEvent
         k.x2_bound = a->x2_bound;
     }
     k.tail_first = 0x7fffffff; k.tail_splits = 1; k.tail_sps = 0; k.tail_rows = 0;
+    k.cut_chunk = cfg.wide ? cfg.cut_chunk : 0;
     if (cfg.tail_tiles) {
         k.tail_first = cfg.tail_first; k.tail_splits = cfg.tail_splits; k.tail_sps = cfg.tail_sps;
         k.tail_rows = cfg.tail_tiles * cfg.bm;

@@ -201,7 +201,8 @@ int evc_conv_pack_weights(const float* w, void* packed, int Co, int Ci, int KH, 
  * the same up to fp32 summation order): "wide_tiles" (default 1: 256-pixel row tiles on large unsplit grids), "row_reuse"
  * (default 1: the row-reuse kernel for 3x3 filters), "tail_split" (default 1: K-split tail of 1.x / 2.x-round grids), "wide256"
  * (default 1: conv_wide_kernel, the 256 x 192 one-workgroup-per-CU f16x3 kernel, on grids of at least one full round), "wide_mid"
- * (default 1: the same kernel with a uniform K split on grids below one round).
+ * (default 1: the same kernel with a uniform K split on grids below one round), "wide_cut" (default 1: on grids of 129..255 such
+ * workgroups every tile is cut into a long and a short K piece so that the idle CUs take the short ones).
  * Returns EVC_EINVAL for an unknown name. */
 int evc_conv_set_option(const char* name, int value);
 /* Name of the kernel template instance evc_conv2d_nhwc_f32 launches for these arguments, as rocprofv3 --kernel-trace --stats

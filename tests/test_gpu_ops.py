@@ -227,6 +227,7 @@ def test_conv_split_k_is_deterministic_and_matches_unsplit(L, arith, B, H, W, C0
     (9, 8, 8, 384, 384, 160, 0, 0),       # W = 8 (a tile spans two images), two channel tiles, partial last pixel tile
     (9, 16, 16, 192, 384, 64, 64, 0),     # W = 16, two channel tiles, two sources
     (5, 128, 128, 96, 192, 64, 0, 0),     # 640 tiles: one round + a K-split tail
+    (9, 64, 64, 192, 192, 192, 192, 0),   # wide kernel, 144 tiles: two unequal K pieces, each with half of the 24 1x1 chunks
     (8, 64, 64, 64, 128, 16, 0, 0),       # unsplit, a single 1x1 chunk, 128-wide channel tile
 ])
 def test_conv3x3_with_fused_1x1_operand(L, B, H, W, C, Co, C2a, C2b, splits):
@@ -283,6 +284,7 @@ def test_conv3x3_with_fused_1x1_operand(L, B, H, W, C, Co, C2a, C2b, splits):
     (5, 128, 128, 48, 0, 192, "plain", "320 tiles, 3 chunks: tail too short to split -> a second round of whole tiles"),
     (9, 64, 64, 96, 0, 384, "gn", "288 workgroups over two channel tiles: one round + a split tail"),
     (9, 64, 64, 64, 0, 192, "plain", "144 tiles, 4 chunks: below one round, unsplit"),
+    (9, 64, 64, 128, 64, 192, "gn", "144 tiles, 12 chunks: below one round, two UNEQUAL K pieces per tile (option wide_cut) + combine"),
     (9, 32, 32, 128, 64, 384, "gn", "72 tiles, 12 chunks: below one round, uniform 3-way K split + combine"),
     (64, 16, 16, 64, 0, 384, "gn", "W = 16: sixteen image rows per tile"),
 ])
