@@ -197,7 +197,15 @@ __device__ __forceinline__ void split2h(float v, _Float16& a, _Float16& b) {
     b = (_Float16)(v - (float)a);
 }
 
-template <int D, int WAVES>
+typedef __attribute__((address_space(3))) void attn_lds_void;
+typedef const __attribute__((address_space(1))) void attn_glb_void;
+
+// PRE = true: K / V arrive already scaled, split and laid out -- one contiguous image per (sample, head, 32-key tile) in exactly
+// the LDS layout below, written once per launch by attention_kv_planes_kernel -- and a tile is staged by LDS-DMA
+// (global_load_lds_dwordx4: no registers, no conversion arithmetic, no ds_write) into one of TWO LDS images, the copy of tile
+// t + 1 running under the MFMAs of tile t with a single barrier per tile.  Same numbers as PRE = false (the conversion is the
+// same code, run once per tile instead of once per tile and query block).
+template <int D, int WAVES, bool PRE = false>
 __global__ __launch_bounds__(64 * WAVES, 1) void attention_f16_kernel(const float* __restrict__ q,
                                                                       const float* __restrict__ k,
                                                                       const float* __restrict__ v, int ld,
@@ -205,16 +213,19 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_f16_kernel(const floa
                                                                       float scale, const unsigned* __restrict__ bounds,
                                                                       int kparts, int tiles_per_part,
                                                                       float* __restrict__ part_o,
-                                                                      float* __restrict__ part_ml) {
+                                                                      float* __restrict__ part_ml,
+                                                                      const char* __restrict__ kv_planes) {
     constexpr int NKS = D / 16;            // k-steps of the QK^T product
     constexpr int DT = D / 32;             // 32-wide d tiles of the PV product
     constexpr int NT = 64 * WAVES;
     constexpr int KROW = 2 * D + 16;       // bytes per key row of a K plane: D/8 + 1 slots (odd)
     constexpr int VROW = 64 + 16;          // bytes per d row of a V^T plane: 32 key positions + 1 slot
     constexpr int KPL = 32 * KROW, VPL = D * VROW;
+    constexpr int TILE_BYTES = 2 * KPL + 2 * VPL;
+    static_assert(!PRE || WAVES == 4, "the pre-converted path stages with 256 threads");
     extern __shared__ __attribute__((aligned(16))) char smem_h[];
-    char* const Ks = smem_h;               // [2 planes][32 keys][KROW]
-    char* const Vs = smem_h + 2 * KPL;     // [2 planes][D][VROW]
+    char* Ks = smem_h;                     // [2 planes][32 keys][KROW]      (PRE: + a second image behind the first)
+    char* Vs = smem_h + 2 * KPL;           // [2 planes][D][VROW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -328,12 +339,35 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_f16_kernel(const floa
         }
     };
 
-    if (k_begin < k_end) load_tile(k_begin);
+    // PRE: LDS-DMA of one tile image, 16 bytes per lane, 1 KiB per wave and instruction (wave w moves bytes
+    // [4096 j + 1024 w, + 1024) of the image for j = 0, 1, ...)
+    const char* const tile0 = PRE ? kv_planes + ((size_t)(b * gridDim.y + h) * ((N + 31) / 32)) * TILE_BYTES : nullptr;
+    auto dma_tile = [&](int k0, int buf) {
+        const char* src = tile0 + (size_t)(k0 >> 5) * TILE_BYTES + wave * 1024 + lane * 16;
+        char* dst = smem_h + buf * TILE_BYTES + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < (TILE_BYTES + 4095) / 4096; ++j)
+            if (4096 * j + 1024 * wave < TILE_BYTES)            // wave-uniform (TILE_BYTES is a multiple of 1024)
+                __builtin_amdgcn_global_load_lds((attn_glb_void*)(src + 4096 * j), (attn_lds_void*)(dst + 4096 * j), 16, 0, 0);
+    };
+    static_assert(TILE_BYTES % 1024 == 0, "tile image = whole wave-instructions");
+    if (k_begin < k_end) {
+        if constexpr (PRE) dma_tile(k_begin, 0); else load_tile(k_begin);
+    }
     for (int k0 = k_begin; k0 < k_end; k0 += 32) {
-        __syncthreads();   // previous tile fully consumed
-        store_tile();
-        __syncthreads();
-        if (k0 + 32 < k_end) load_tile(k0 + 32);       // in flight during this tile's MFMAs
+        if constexpr (PRE) {
+            const int buf = ((k0 - k_begin) >> 5) & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the tile has landed ...
+            __syncthreads();                                    // ... and everybody's; the other image is fully consumed
+            if (k0 + 32 < k_end) dma_tile(k0 + 32, buf ^ 1);    // copied during this tile's MFMAs
+            Ks = smem_h + buf * TILE_BYTES;
+            Vs = Ks + 2 * KPL;
+        } else {
+            __syncthreads();   // previous tile fully consumed
+            store_tile();
+            __syncthreads();
+            if (k0 + 32 < k_end) load_tile(k0 + 32);       // in flight during this tile's MFMAs
+        }
 
         // ---- S^T tile: rows = keys (registers), col = query (lane) ----
         f32x16 s;
@@ -349,16 +383,28 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_f16_kernel(const floa
         }
 
         // ---- online softmax over this tile's 32 keys (16 here, 16 in lane ^ 32) ----
+        // LAZY reference: the running reference m_run only moves when a tile's maximum exceeds it by more than LAZY_TAU, so the
+        // rescale of the 6 x 16 output accumulators (a wave-uniform branch any of the 32 queries can trigger) runs on a few
+        // tiles instead of on nearly all of them; in between the weights are exp(s - m_run) <= e^LAZY_TAU = 33 instead of <= 1,
+        // which the 2^10 scale of P still keeps inside fp16's range (33 * 1024 < 65504) at the same 2^-22 split accuracy.
+        // The normalisation (l_run) and the key-part merge use the same reference, so the result is the same softmax.
+        constexpr float LAZY_TAU = 3.5f;
         float m_tile = -INFINITY;
+        if (k0 + 32 > N) {                             // wave-uniform: only a ragged last tile has keys to mask
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            s[r] = key < N ? s[r] * s_mul : -INFINITY;
-            m_tile = fmaxf(m_tile, s[r]);
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                s[r] = key < N ? s[r] * s_mul : -INFINITY;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] *= s_mul;
         }
-        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
-        const float m_new = fmaxf(m_run, m_tile);      // finite: every tile holds at least one valid key
-        const float alpha = __expf(m_run - m_new);     // exp(-inf) = 0 on the first tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, s[r]);
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));           // finite: every tile holds at least one valid key
+        const float m_new = m_tile > m_run + LAZY_TAU ? m_tile : m_run;     // first tile: m_run = -inf -> m_tile
+        const float alpha = __expf(m_run - m_new);     // exp(-inf) = 0 on the first tile, exactly 1 while the reference stays
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -367,7 +413,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_f16_kernel(const floa
         }
         l_run = l_run * alpha + psum;
         m_run = m_new;
-        if (__any(alpha != 1.0f)) {                    // wave-uniform: once the running maxima settle, no rescale
+        if (__any(alpha != 1.0f)) {                    // wave-uniform: only when some query's reference moved
 #pragma unroll
             for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -422,6 +468,63 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_f16_kernel(const floa
             }
     }
 }
+
+// K / V of one launch -> the tile images attention_f16_kernel<D, 4, true> stages by LDS-DMA: per (sample, head, 32-key tile)
+// [2 planes][32 keys][KROW] of K and [2 planes][D][VROW] of V^T (keys in the permuted order of the PV product's B fragment),
+// scaled by the same powers of two and split into the same two fp16 planes as the in-kernel conversion (split2h).  The row
+// pads are never read.  grid (tiles, heads, B), block 256.
+template <int D>
+__global__ __launch_bounds__(256) void attention_kv_planes_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                                  int ld, int N, const unsigned* __restrict__ bounds,
+                                                                  char* __restrict__ planes) {
+    constexpr int NT = 256;
+    constexpr int KROW = 2 * D + 16, VROW = 64 + 16;
+    constexpr int KPL = 32 * KROW, VPL = D * VROW;
+    constexpr int TILE_BYTES = 2 * KPL + 2 * VPL;
+    const int tid = threadIdx.x, tile = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int k0 = tile * 32;
+    const size_t base = (size_t)b * N * ld + (size_t)h * D;
+    char* const Ks = planes + ((size_t)(b * gridDim.y + h) * gridDim.x + tile) * TILE_BYTES;
+    char* const Vs = Ks + 2 * KPL;
+    const float sk = pow2_scale_for(__uint_as_float(bounds[1]), 9);
+    const float sv = pow2_scale_for(__uint_as_float(bounds[2]), 9);
+    for (int u = tid; u < 32 * (D / 8); u += NT) {                // K unit = (key, 8-channel chunk)
+        const int row = u / (D / 8), ch = u - row * (D / 8);
+        const int key = k0 + row;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+        if (key < N) {
+            const float* kp = k + base + (size_t)key * ld + 8 * ch;
+            a = *reinterpret_cast<const float4*>(kp);
+            c = *reinterpret_cast<const float4*>(kp + 4);
+        }
+        const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        h16x8 p1, p2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { _Float16 uu, ww; split2h(x[j] * sk, uu, ww); p1[j] = uu; p2[j] = ww; }
+        char* dst = Ks + row * KROW + 16 * ch;
+        *reinterpret_cast<h16x8*>(dst) = p1;
+        *reinterpret_cast<h16x8*>(dst + KPL) = p2;
+    }
+    for (int u = tid; u < 8 * D; u += NT) {                       // V unit = (4 consecutive keys, channel d), lanes along d
+        const int g = u / D, d = u - g * D;
+        h16x4 p1, p2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = k0 + 4 * g + e;
+            const float x = key < N ? v[base + (size_t)key * ld + d] : 0.f;
+            _Float16 uu, ww;
+            split2h(x * sv, uu, ww);
+            p1[e] = uu; p2[e] = ww;
+        }
+        const int pos = 16 * (g >> 2) + 8 * (g & 1) + 4 * ((g >> 1) & 1);
+        char* dst = Vs + d * VROW + 2 * pos;
+        *reinterpret_cast<h16x4*>(dst) = p1;
+        *reinterpret_cast<h16x4*>(dst + VPL) = p2;
+    }
+}
+
+template <int D>
+constexpr long long attention_tile_bytes() { return 2LL * 32 * (2 * D + 16) + 2LL * D * 80; }
 
 // out[b][n][h*D + d] = sum_p w_p * o_p[d] / sum_p w_p * l_p,  w_p = exp(m_p - max_p m_p): the exact online-softmax
 // merge of the key parts (same formula the kernel applies tile by tile).  One thread per (b, n, h, 4 channels).
@@ -510,6 +613,17 @@ AttnPlan attention_plan_f16(int B, int heads, int N) {
     return p;
 }
 
+int g_attn_pre = 1;       // run-time switch (evc_attention_set_option "kv_planes"): K / V converted once per launch (A/B)
+
+// bytes of the key-part buffers at the head of the workspace (part_o | part_ml), rounded to 16
+long long attention_parts_bytes(int B, int heads, int N, int D) {
+    const int kp = attention_plan(B, heads, N, true).kparts, kp16 = attention_plan_f16(B, heads, N).kparts;
+    const int kparts = kp > kp16 ? kp : kp16;
+    if (kparts <= 1) return 0;
+    const long long n = (long long)kparts * B * N * heads * ((long long)D + 2) * (long long)sizeof(float);
+    return (n + 15) / 16 * 16;
+}
+
 // attention_kernel<256, *> stages 2 x 32 x 260 floats = 65 KB: above the 64 KB a kernel gets without asking
 template <int D, int WAVES>
 int launch_f32(dim3 grid, size_t lds, hipStream_t st, const float* q, const float* k, const float* v, int ld, float* out, int ld_out,
@@ -545,16 +659,36 @@ int launch(const float* q, const float* k, const float* v, int ld, float* out, i
     // tiny key sets (N < 128: the 8x8 level) stay on the f32 kernel: with two key tiles there is nothing to amortise the
     // fp16 conversion of K / V over (measured B=9, 8x8: 26 us f32 vs 39 us fp16 split; 16x16: 81 vs 29; 32x32: 260 vs 155)
     if constexpr (F16_OK) if (use_f16) {
-        const size_t lds16 = (size_t)2 * 32 * (2 * D + 16) + (size_t)2 * D * 80;
-        if (waves == 4)
+        const size_t lds16 = (size_t)attention_tile_bytes<D>();
+        // with a workspace: K / V converted once per launch into tile images (behind the key-part buffers), staged by LDS-DMA
+        // (from 512 keys on: below that the pre-pass launch costs more than the conversions it saves -- B = 9, 256 keys, 3 heads:
+        // 36 us with it, 29 without; 1024 keys, 2 heads: 110 vs 127 -- profiles/r04_attn_kv_planes_ab.log)
+        if (waves == 4 && ws && g_attn_pre && N >= 512) {
+            const int ntiles = (N + 31) / 32;
+            char* planes = reinterpret_cast<char*>(ws) + attention_parts_bytes(B, heads, N, D);
+            hipLaunchKernelGGL((attention_kv_planes_kernel<D>), dim3(ntiles, heads, B), dim3(256), 0, st, k, v, ld, N, bounds, planes);
+            if (2 * lds16 > 64 * 1024) {
+                static unsigned long long done = 0;                   // one bit per device id
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess) return EVC_ELAUNCH;
+                const unsigned long long bit = 1ULL << (dev & 63);
+                if (!(__atomic_load_n(&done, __ATOMIC_ACQUIRE) & bit)) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_kernel<D, 4, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds16)) != hipSuccess) return EVC_ELAUNCH;
+                    __atomic_fetch_or(&done, bit, __ATOMIC_RELEASE);
+                }
+            }
+            hipLaunchKernelGGL((attention_f16_kernel<D, 4, true>), grid, dim3(256), 2 * lds16, st, q, k, v, ld, out, ld_out, N, scale,
+                               bounds, pl.kparts, pl.tiles_per_part, part_o, part_ml, planes);
+        } else if (waves == 4)
             hipLaunchKernelGGL((attention_f16_kernel<D, 4>), grid, dim3(256), lds16, st, q, k, v, ld, out, ld_out, N, scale,
-                               bounds, pl.kparts, pl.tiles_per_part, part_o, part_ml);
+                               bounds, pl.kparts, pl.tiles_per_part, part_o, part_ml, nullptr);
         else if (waves == 2)
             hipLaunchKernelGGL((attention_f16_kernel<D, 2>), grid, dim3(128), lds16, st, q, k, v, ld, out, ld_out, N, scale,
-                               bounds, pl.kparts, pl.tiles_per_part, part_o, part_ml);
+                               bounds, pl.kparts, pl.tiles_per_part, part_o, part_ml, nullptr);
         else
             hipLaunchKernelGGL((attention_f16_kernel<D, 1>), grid, dim3(64), lds16, st, q, k, v, ld, out, ld_out, N, scale,
-                               bounds, pl.kparts, pl.tiles_per_part, part_o, part_ml);
+                               bounds, pl.kparts, pl.tiles_per_part, part_o, part_ml, nullptr);
     }
     if (!use_f16) {
         const int rc = waves == 4 ? launch_f32<D, 4>(grid, lds, st, q, k, v, ld, out, ld_out, N, scale, pl.kparts, pl.tiles_per_part, part_o, part_ml)
@@ -599,10 +733,21 @@ extern "C" int evc_attention_f32(const float* q, const float* k, const float* v,
 
 extern "C" long long evc_attention_workspace_bytes(int B, int heads, int N, int D) {
     if (B <= 0 || heads <= 0 || N <= 0 || D <= 0) return EVC_EINVAL;
-    const int kp = attention_plan(B, heads, N, true).kparts, kp16 = attention_plan_f16(B, heads, N).kparts;
-    const int kparts = kp > kp16 ? kp : kp16;          // one workspace serves both kernels
-    if (kparts <= 1) return 0;
-    return (long long)kparts * B * N * heads * ((long long)D + 2) * (long long)sizeof(float);
+    long long n = attention_parts_bytes(B, heads, N, D);          // key-part buffers: one size serves both kernels
+    // + the K / V tile images of the fp16 kernel (evc_attention_f16x3_f32 with >= 128 keys and a head width it covers)
+    if (N >= 128 && D <= 192 && (D == 32 || D == 64 || D == 128 || D == 192))
+        n += (long long)B * heads * ((N + 31) / 32) * (2LL * 32 * (2 * D + 16) + 2LL * D * 80);
+    return n;
+}
+
+extern "C" int evc_attention_set_option(const char* name, int value) {
+    if (!name) return EVC_EINVAL;
+    const char* s = "kv_planes";
+    int i = 0;
+    while (s[i] && s[i] == name[i]) ++i;
+    if (s[i] || name[i]) return EVC_EINVAL;
+    g_attn_pre = value;
+    return EVC_OK;
 }
 
 extern "C" int evc_attention_ws_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out,

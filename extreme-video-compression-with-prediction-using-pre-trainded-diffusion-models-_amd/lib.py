@@ -127,6 +127,7 @@ HIP_SYMBOLS = {
     "evc_attention_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                   c_float, c_void_p]),
     "evc_attention_workspace_bytes": (c_longlong, [c_int, c_int, c_int, c_int]),
+    "evc_attention_set_option": (c_int, [c_char_p, c_int]),
     "evc_attention_ws_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_float, c_void_p, c_void_p]),
     "evc_frame_group_norm_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_float, c_void_p]),
@@ -644,6 +645,12 @@ def conv_workspace_bytes(B, H, W, Ci, Co, KH, KW, splits=0, arith=None):
     a = ConvArgs(d, None, Ci, 0, 0, 0, None, None, ACT_NONE, d, None, None, 0, 1.0, ACT_NONE, d, Co, B, H, W, Co, KH,
                  KW, splits, None, default_arith() if arith is None else arith, None)
     return hip_lib(require_device=False).evc_conv_workspace_bytes(ctypes.byref(a))
+
+
+def attention_set_option(name, value):
+    """A/B switch of the attention kernels (include/evc_hip.h: "kv_planes")."""
+    if hip_lib().evc_attention_set_option(name.encode(), int(value)) != 0:
+        raise EvcKernelError(f"unknown attention option {name!r}")
 
 
 def attention(qkv, C, heads, out=None, bounds=None):

@@ -232,8 +232,13 @@ int evc_attention_f32(const float* q, const float* k, const float* v, int ld_qkv
 /* The same with a workspace of evc_attention_workspace_bytes() bytes (0 = none needed): launches that would leave
  * SIMDs idle split the KEY range over several workgroups (each leaves an unnormalised partial + running max / sum)
  * and a merge kernel applies the exact online-softmax combination.  Results equal evc_attention_f32 up to fp32
- * rounding of the merge. */
+ * rounding of the merge.  The workspace also holds the fp16 kernel's K / V tile images (evc_attention_set_option), so it is
+ * non-zero whenever N >= 128 and D is one of 32 / 64 / 128 / 192. */
 long long evc_attention_workspace_bytes(int B, int heads, int N, int D);
+/* A/B switch: "kv_planes" (default 1) -- evc_attention_f16x3_f32 with >= 512 keys converts K / V ONCE per launch into per-tile
+ * images of its LDS layout (a pre-pass into the workspace) and stages them by LDS-DMA, instead of converting every 32-key tile
+ * again in every query block.  Same numbers either way.  Returns EVC_EINVAL for an unknown name. */
+int evc_attention_set_option(const char* name, int value);
 int evc_attention_ws_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out, int B,
                          int heads, int N, int D, float scale, float* ws, void* stream);
 

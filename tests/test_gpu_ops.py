@@ -646,6 +646,37 @@ def test_attention_key_split_matches_single_pass(L):
     assert lib.evc_attention_ws_f32(*args, L.fptr(out_ws), C, B, heads, N, D, D ** -0.5, None, L.stream_ptr()) == -1
 
 
+@pytest.mark.parametrize("B,heads,N,D", [(9, 2, 1024, 192), (2, 3, 576, 192), (1, 2, 1000, 192), (2, 1, 512, 128), (3, 2, 640, 64),
+                                         (2, 4, 520, 32), (2, 3, 256, 192)])
+def test_attention_kv_planes_equal_the_in_kernel_conversion(L, B, heads, N, D):
+    """evc_attention_f16x3_f32 with K / V converted ONCE per launch into tile images staged by LDS-DMA (option "kv_planes",
+    the default) against the same kernel converting every tile in every query block: the same conversion code on the same
+    numbers, so the outputs are EQUAL bit for bit -- incl. ragged last key tiles (N = 1000, 520), key parts + merge, every head
+    width the fp16 kernel covers, and a shape below the 512 keys from which the pre-pass is used -- and both match fp64."""
+    C = heads * D
+    q = rnd(47, B, N, C)
+    k = rnd(48, B, N, C) * torch.linspace(0.3, 3.0, N)[None, :, None]
+    v = rnd(49, B, N, C)
+    qkv = torch.cat([q, k, v], 2).cuda()
+    bounds = qkv_bounds(L, qkv, C)
+    assert L.hip_lib().evc_attention_workspace_bytes(B, heads, N, D) >= B * heads * ((N + 31) // 32) * (64 * (2 * D + 16) + 160 * D)
+    try:
+        L.attention_set_option("kv_planes", 0)
+        base = L.attention(qkv, C, heads, bounds=bounds)
+    finally:
+        L.attention_set_option("kv_planes", 1)
+    out = L.attention(qkv, C, heads, bounds=bounds)
+    assert torch.equal(out, base)
+    assert torch.equal(L.attention(qkv, C, heads, bounds=bounds), out)            # and deterministic
+    if B * N <= 2048:
+        qh, kh, vh = [t.double().reshape(B, N, heads, D).permute(0, 2, 1, 3) for t in (q, k, v)]
+        w = torch.softmax(torch.einsum("bhqd,bhkd->bhqk", qh, kh) * (D ** -0.5), dim=-1)
+        ref = torch.einsum("bhqk,bhkd->bhqd", w, vh).permute(0, 2, 1, 3).reshape(B, N, C).float()
+        assert rel(out, ref) < 2e-5
+    with pytest.raises(L.EvcKernelError):
+        L.attention_set_option("no_such_option", 1)
+
+
 @pytest.mark.parametrize("inverse,simplified", [(False, False), (True, False), (False, True), (True, True)])
 def test_gdn_against_formula(L, inverse, simplified):
     """GDN / IGDN / GDN1 (ELICUtilis/layers/gdn.py:62-77, 95-106) against the formula in fp64, with compressai's
