@@ -12,6 +12,10 @@ What is restated here, and what pins it:
   ``models/better/op/upfirdn2d.py``).  PINNED: ``tests/golden/make_goldens.py`` imports
   the reference itself in the build container and stores its outputs as fixtures under
   ``tests/golden/``; ``tests/test_oracle_goldens.py`` checks this restatement against them.
+* ``scorenet_spade.py`` / ``unet_ddpm.py`` / ``scorenet_pseudo3d.py`` -- the alternative score networks (SPADE conditioning;
+  ``models/unet.py``; the ``is3d`` / ``pseudo3d`` branches with ``models/better/layers3d.py``: archs ``unetmorepseudo3d`` and
+  ``unetmore3d``).  PINNED the same way (``forward_spade.npz``, ``unet_ddpm*.npz``, ``forward_pseudo3d.npz``,
+  ``forward_conv3d.npz``: outputs + forward-hook taps of every module).
 * ``elic.py`` / ``entropy.py`` / ``rans.py`` -- the ELIC key-frame codec (reference
   ``Network.py``, ``ELICUtilis/layers/layers.py``, ``Inference.py``) and the entropy
   coder of third-party ``compressai==1.1.5`` (``requirements.txt:17``; not vendored, not
