@@ -764,3 +764,27 @@ def test_pseudo3d_network_in_the_sampler_against_the_oracle(arch, name, seed):
     ref = OS.ddpm(xT.clone(), lambda x, t: O3.forward(p, d, x, t, cond=cond, arch=arch), OSch.base_schedule(), subsample_steps=10,
                   noise_fn=lambda i, x: noises[i])[0]
     assert rel(out, ref.numpy()) < 2e-4
+
+
+@pytest.mark.parametrize("arch", ["unetmorepseudo3d", "unetmore3d"])
+def test_3d_networks_at_the_shipped_frame_counts_against_the_oracle(arch):
+    """The 3-D archs at the shipped clip geometry -- 5 generated + 2 conditioning frames, 64 x 64, three levels (attention at
+    16 x 16, head width 64) -- so that the frame axis is 7 -> 5, the time convolution's "image" is 7 rows x 4096 columns and the
+    3-D GroupNorm runs over 7 x 64 x 64 pixels; against the pinned oracle (oracle/scorenet_pseudo3d.py) on seeded weights."""
+    import evc_amd  # noqa: F401
+    from evc_amd import synthetic
+    from evc_amd.scorenet import build_score_network
+    from oracle import scorenet_pseudo3d as O3
+    torch.set_num_threads(16)
+    d = O3.Dims(ngf=64, ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[16], n_head_channels=64, image_size=64,
+                num_frames=5, num_frames_cond=2)
+    cfg = make_config(d.ngf, d.n_head_channels, d.image_size)
+    cfg.model.arch, cfg.model.ch_mult, cfg.model.num_res_blocks, cfg.model.attn_resolutions = arch, d.ch_mult, 1, d.attn_resolutions
+    p = synthetic.diffusion_state_dict(cfg, 57)
+    assert [k for k, _ in O3.param_shapes(d, arch=arch)] == list(p)
+    net = build_score_network(cfg, p)
+    x, cond = rnd(58, 2, 15, 64, 64), rnd(59, 2, 6, 64, 64)
+    out = net(x.cuda(), torch.tensor([321, 5]), cond=cond.cuda())
+    ref = O3.forward(p, d, x, torch.tensor([321, 5]), cond=cond, arch=arch)
+    assert out.shape == (2, 15, 64, 64)
+    assert rel(out, ref.numpy()) < 1e-4
