@@ -50,6 +50,23 @@ def test_cli_end_to_end_synthetic(tmp_path, monkeypatch):
     assert np.load(d / "psnr_0.npy").shape[0] == 2
 
 
+def test_cli_with_the_pseudo3d_network_selected_by_config_mod(tmp_path, monkeypatch):
+    """``--config_mod model.arch=unetmorepseudo3d`` (the reference's override grammar, city_sender.py:138-170): the CLI builds
+    the pseudo-3-D score network through ``build_score_network`` from the synthetic checkpoint and decodes a clip end to end."""
+    import evc_amd  # noqa: F401
+    from evc_amd import cli
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.chdir(tmp_path)
+    out = tmp_path / "out"
+    cli.main(["--config", os.path.join(repo, "configs", "mine.yml"), "--synthetic", "--exp", str(tmp_path / "exp"),
+              "--data_npy", "missing.npy", "--output_path", str(out), "--start_idx", "0", "--end_idx", "0", "--batch", "1",
+              "--subsample", "2", "--q", "3",
+              "--config_mod", "model.arch=unetmorepseudo3d model.ngf=32 model.n_head_channels=32 model.attn_resolutions=[16]"])
+    arr = np.load(out / "output_0" / "city_output_npy_idx0_q3_thr0.00.npy")
+    assert arr.shape == (2 * 128, 30 * 128, 3) and np.isfinite(arr).all() and arr.min() >= 0 and arr.max() <= 1
+    assert np.load(out / "output_0" / "psnr_frames_0.npy").shape == (1, 30)
+
+
 def test_cli_quality_sweep_q0_to_q5(tmp_path, monkeypatch):
     """BASELINE.json configs[3] -- the quality sweep q0..q5 through the CLI (`--q 0 1 2 3 4 5`; the reference hard-codes
     q4, q5: city_sender.py:504): one ELIC model per quality index, per-q outputs under the reference's file names, one
