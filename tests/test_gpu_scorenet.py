@@ -788,3 +788,18 @@ def test_3d_networks_at_the_shipped_frame_counts_against_the_oracle(arch):
     ref = O3.forward(p, d, x, torch.tensor([321, 5]), cond=cond, arch=arch)
     assert out.shape == (2, 15, 64, 64)
     assert rel(out, ref.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("arch,name,seed", ARCHS_3D)
+def test_3d_networks_replayed_from_hip_graphs_equal_eager(arch, name, seed):
+    """``use_graphs=True`` (forwards replayed from a captured HIP graph, ``bench.py --graphs``) with the 3-D networks: their host
+    code allocates and repeats coefficient rows inside the capture; outputs must equal the eager launches bit for bit, also on
+    a second input through the same graph."""
+    eager, d, p, O3 = build_pseudo3d(arch, seed)
+    import copy
+    from evc_amd.scorenet import build_score_network
+    graph = build_score_network(copy.deepcopy(eager.config), p, use_graphs=True)
+    x, cond = rnd(92, 2, 9, 16, 16).cuda(), rnd(93, 2, 6, 16, 16).cuda()
+    lab = torch.tensor([430, 7])
+    assert torch.equal(graph(x, lab, cond=cond), eager(x, lab, cond=cond))
+    assert torch.equal(graph(0.5 * x, lab, cond=cond), eager(0.5 * x, lab, cond=cond))
