@@ -12,6 +12,10 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
 def pytest_configure(config):
+    # CPU oracle forwards: a GPU box shows all 128 host cores but a job's share is 16, and torch at 128 threads runs the oracle
+    # network 8x SLOWER than at 16 (bench.py cpu_baseline probe: 1.92 s vs 0.25 s per forward) -- one setting for every test
+    import os
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: takes more than a few seconds on CPU")
 

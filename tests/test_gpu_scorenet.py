@@ -175,9 +175,22 @@ def test_every_conv_launch_of_the_full_size_forward_against_torch(full_net):
     """Walk every DISTINCT convolution launch the full-size forward makes at the benchmark's batch sizes (B = 9:
     configs[1]; B = 32: configs[4]; B = 5, 6: a rank of configs[2]; B = 8: the CLI's default batch) -- shape, source
     split, on-load transform, residual, arithmetic -- and run each through the C ABI exactly as the network does (same
-    tile / split-K / kernel choice, which depend on B) against torch's fp32 convolution on the same device."""
+    tile / split-K / kernel choice, which depend on B) against torch's fp32 arithmetic on the same device."""
     import torch.nn.functional as F
     from evc_amd import lib as L
+
+    def conv_ref(x, w, bias, K):
+        """torch fp32 convolution of an NHWC tensor in shift-and-matmul form (one fp32 GEMM per filter tap): the same numbers
+        as F.conv2d up to summation order, without MIOpen's per-shape kernel search and JIT -- > 200 distinct shapes cost
+        1.5 - 3 minutes of it on a fresh box, which is what made this test's duration vary from box to box."""
+        Bx, Hx, Wx, _ = x.shape
+        xp = F.pad(x, (0, 0, K // 2, K // 2, K // 2, K // 2))
+        out = None
+        for ty in range(K):
+            for tx in range(K):
+                t = xp[:, ty:ty + Hx, tx:tx + Wx, :] @ w[:, :, ty, tx].t()
+                out = t if out is None else out + t
+        return out if bias is None else out + bias
     seen = {}
     for B in (5, 6, 8, 9, 32):
         x = rnd(900, B, 15, 128, 128).cuda()
@@ -229,9 +242,9 @@ def test_every_conv_launch_of_the_full_size_forward_against_torch(full_net):
             xin = xin * coef[0][:, None, None, :] + coef[1][:, None, None, :]
         if call["act_in"] == L.ACT_SILU:
             xin = F.silu(xin)
-        ref = F.conv2d(xin.permute(0, 3, 1, 2), w, bias, padding=K // 2).permute(0, 2, 3, 1)
+        ref = conv_ref(xin, w, bias, K)
         if x2 is not None:
-            ref = ref + F.conv2d(x2t.permute(0, 3, 1, 2), w2).permute(0, 2, 3, 1)
+            ref = ref + conv_ref(x2t, w2, None, 1)
         if res is not None:
             ref = ref + res
         ref = ref * call["out_scale"]
