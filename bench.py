@@ -35,6 +35,10 @@ import os
 import sys
 import time
 
+# dmabuf IPC (RCCL / device-tensor sharing across the ranks of a node): the only mode this host driver supports; normally already
+# exported by the environment, set here before the HIP runtime starts in case a launcher dropped it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 
