@@ -481,23 +481,52 @@ __global__ __launch_bounds__(256) void attention_kv_planes_kernel(const float* _
     constexpr int KROW = 2 * D + 16, VROW = 64 + 16;
     constexpr int KPL = 32 * KROW, VPL = D * VROW;
     constexpr int TILE_BYTES = 2 * KPL + 2 * VPL;
+    // the image is assembled in LDS (the transposed V^T pieces are 8-byte writes 80 bytes apart) and leaves as one contiguous copy
+    extern __shared__ __attribute__((aligned(16))) char img[];
     const int tid = threadIdx.x, tile = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int k0 = tile * 32;
     const size_t base = (size_t)b * N * ld + (size_t)h * D;
-    char* const Ks = planes + ((size_t)(b * gridDim.y + h) * gridDim.x + tile) * TILE_BYTES;
+    char* const Ks = img;
     char* const Vs = Ks + 2 * KPL;
+    for (int i = tid; i < 2 * 32 + 2 * D; i += NT) {              // the row pads are copied too: keep them defined
+        char* row = i < 64 ? Ks + i * KROW + 2 * D : Vs + (i - 64) * VROW + 64;
+        *reinterpret_cast<float4*>(row) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const float sk = pow2_scale_for(__uint_as_float(bounds[1]), 9);
     const float sv = pow2_scale_for(__uint_as_float(bounds[2]), 9);
-    for (int u = tid; u < 32 * (D / 8); u += NT) {                // K unit = (key, 8-channel chunk)
+    // all loads first (they are independent: one memory round trip instead of one per unit), then convert + place
+    constexpr int KU = (32 * (D / 8) + NT - 1) / NT;             // K unit = (key, 8-channel chunk)
+    constexpr int VU = (8 * D + NT - 1) / NT;                     // V unit = (4 consecutive keys, channel d), lanes along d
+    float4 kreg[KU][2];
+    float vreg[VU][4];
+#pragma unroll
+    for (int i = 0; i < KU; ++i) {
+        const int u = tid + NT * i;
         const int row = u / (D / 8), ch = u - row * (D / 8);
         const int key = k0 + row;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-        if (key < N) {
+        kreg[i][0] = kreg[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u < 32 * (D / 8) && key < N) {
             const float* kp = k + base + (size_t)key * ld + 8 * ch;
-            a = *reinterpret_cast<const float4*>(kp);
-            c = *reinterpret_cast<const float4*>(kp + 4);
+            kreg[i][0] = *reinterpret_cast<const float4*>(kp);
+            kreg[i][1] = *reinterpret_cast<const float4*>(kp + 4);
         }
-        const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+    }
+#pragma unroll
+    for (int i = 0; i < VU; ++i) {
+        const int u = tid + NT * i;
+        const int g = u / D, d = u - g * D;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = k0 + 4 * g + e;
+            vreg[i][e] = (u < 8 * D && key < N) ? v[base + (size_t)key * ld + d] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < KU; ++i) {
+        const int u = tid + NT * i;
+        if (u >= 32 * (D / 8)) break;
+        const int row = u / (D / 8), ch = u - row * (D / 8);
+        const float x[8] = {kreg[i][0].x, kreg[i][0].y, kreg[i][0].z, kreg[i][0].w, kreg[i][1].x, kreg[i][1].y, kreg[i][1].z, kreg[i][1].w};
         h16x8 p1, p2;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { _Float16 uu, ww; split2h(x[j] * sk, uu, ww); p1[j] = uu; p2[j] = ww; }
@@ -505,22 +534,22 @@ __global__ __launch_bounds__(256) void attention_kv_planes_kernel(const float* _
         *reinterpret_cast<h16x8*>(dst) = p1;
         *reinterpret_cast<h16x8*>(dst + KPL) = p2;
     }
-    for (int u = tid; u < 8 * D; u += NT) {                       // V unit = (4 consecutive keys, channel d), lanes along d
+#pragma unroll
+    for (int i = 0; i < VU; ++i) {
+        const int u = tid + NT * i;
+        if (u >= 8 * D) break;
         const int g = u / D, d = u - g * D;
         h16x4 p1, p2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int key = k0 + 4 * g + e;
-            const float x = key < N ? v[base + (size_t)key * ld + d] : 0.f;
-            _Float16 uu, ww;
-            split2h(x * sv, uu, ww);
-            p1[e] = uu; p2[e] = ww;
-        }
+        for (int e = 0; e < 4; ++e) { _Float16 uu, ww; split2h(vreg[i][e] * sv, uu, ww); p1[e] = uu; p2[e] = ww; }
         const int pos = 16 * (g >> 2) + 8 * (g & 1) + 4 * ((g >> 1) & 1);
         char* dst = Vs + d * VROW + 2 * pos;
         *reinterpret_cast<h16x4*>(dst) = p1;
         *reinterpret_cast<h16x4*>(dst + VPL) = p2;
     }
+    __syncthreads();
+    float4* out = reinterpret_cast<float4*>(planes + ((size_t)(b * gridDim.y + h) * gridDim.x + tile) * TILE_BYTES);
+    for (int i = tid; i < TILE_BYTES / 16; i += NT) out[i] = reinterpret_cast<const float4*>(img)[i];
 }
 
 template <int D>
@@ -666,7 +695,7 @@ int launch(const float* q, const float* k, const float* v, int ld, float* out, i
         if (waves == 4 && ws && g_attn_pre && N >= 512) {
             const int ntiles = (N + 31) / 32;
             char* planes = reinterpret_cast<char*>(ws) + attention_parts_bytes(B, heads, N, D);
-            hipLaunchKernelGGL((attention_kv_planes_kernel<D>), dim3(ntiles, heads, B), dim3(256), 0, st, k, v, ld, N, bounds, planes);
+            hipLaunchKernelGGL((attention_kv_planes_kernel<D>), dim3(ntiles, heads, B), dim3(256), lds16, st, k, v, ld, N, bounds, planes);
             if (2 * lds16 > 64 * 1024) {
                 static unsigned long long done = 0;                   // one bit per device id
                 int dev = 0;
