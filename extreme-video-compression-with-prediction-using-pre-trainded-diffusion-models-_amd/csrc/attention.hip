@@ -643,6 +643,7 @@ AttnPlan attention_plan_f16(int B, int heads, int N) {
 }
 
 int g_attn_pre = 1;       // run-time switch (evc_attention_set_option "kv_planes"): K / V converted once per launch (A/B)
+int g_attn_f16_min_keys = 128;   // run-time switch "f16_min_keys": fewest keys for which the fp16-split kernel is used
 
 // bytes of the key-part buffers at the head of the workspace (part_o | part_ml), rounded to 16
 long long attention_parts_bytes(int B, int heads, int N, int D) {
@@ -679,7 +680,7 @@ int launch(const float* q, const float* k, const float* v, int ld, float* out, i
     const size_t lds = (size_t)2 * 32 * (D + 4) * sizeof(float);
     // head widths above 192 stay on the f32 kernel: the fp16 kernel keeps Q (both planes) and O in registers, D/2 + D/2 of them
     constexpr bool F16_OK = D <= 192;
-    const bool use_f16 = F16_OK && bounds && N >= 128;
+    const bool use_f16 = F16_OK && bounds && N >= g_attn_f16_min_keys;
     const AttnPlan pl = (use_f16 && ws) ? attention_plan_f16(B, heads, N) : attention_plan(B, heads, N, ws != nullptr);
     const int waves = pl.waves;
     float* part_o = ws;
@@ -771,12 +772,10 @@ extern "C" long long evc_attention_workspace_bytes(int B, int heads, int N, int 
 
 extern "C" int evc_attention_set_option(const char* name, int value) {
     if (!name) return EVC_EINVAL;
-    const char* s = "kv_planes";
-    int i = 0;
-    while (s[i] && s[i] == name[i]) ++i;
-    if (s[i] || name[i]) return EVC_EINVAL;
-    g_attn_pre = value;
-    return EVC_OK;
+    const auto is = [&](const char* s) { int i = 0; while (s[i] && s[i] == name[i]) ++i; return s[i] == 0 && name[i] == 0; };
+    if (is("kv_planes")) { g_attn_pre = value; return EVC_OK; }
+    if (is("f16_min_keys")) { g_attn_f16_min_keys = value; return EVC_OK; }
+    return EVC_EINVAL;
 }
 
 extern "C" int evc_attention_ws_f32(const float* q, const float* k, const float* v, int ld_qkv, float* out, int ld_out,
